@@ -1,0 +1,166 @@
+/*
+ * reidgan_hip.h — C ABI of libreidgan_hip.so, the MI355X (gfx950) kernel library behind the
+ * ReID-GAN training step (joint FD-GAN + cluster-contrast).
+ *
+ * The reference (daemon-219/ReID-GAN) has no FFI: its hot path is torch.nn modules calling
+ * cuDNN/cuBLAS/ATen.  Each entry point below replaces the ATen/cuDNN work behind one family of
+ * reference call sites (cited per function as FD/ = FD-GAN-master/, CC/ = cluster-contrast-reid-main/).
+ * The host side that binds them with ctypes lives in reid-gan_amd/rg_hip/lib.py; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Contract (every function):
+ *   - returns 0 (RG_OK) or a negative status; rg_last_error() gives the message (thread local);
+ *   - plain pointers to DEVICE memory and sizes; tensors are contiguous fp32 NCHW, labels int64;
+ *   - asynchronous on `stream`; never allocates, frees or synchronises (rg_profile_collect excepted);
+ *   - scratch comes from the caller: `workspace`/`workspace_bytes`, sized by the *_workspace query;
+ *   - pointers must be 16-byte aligned (torch allocations are).
+ */
+#ifndef REIDGAN_HIP_H
+#define REIDGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* rg_stream_t; /* == hipStream_t */
+
+#define RG_OK 0
+#define RG_ERR_INVALID (-1)
+#define RG_ERR_LAUNCH (-2)
+#define RG_ERR_WORKSPACE (-3)
+
+/* activation codes of the fused epilogues */
+#define RG_ACT_NONE 0
+#define RG_ACT_RELU 1
+#define RG_ACT_LEAKY 2
+#define RG_ACT_TANH 3
+
+const char* rg_last_error(void);
+int rg_version(void);
+
+/* ---- per-family launch profiler (HIP events on the launch stream; used by bench.py) ---------- */
+#define RG_FAMILY_COUNT 10 /* conv_fwd, conv_dgrad, conv_wgrad, norm, eltwise, pool, loss, cm, optim, misc */
+int rg_family_count(void);
+int rg_profile_enable(int on);
+int rg_profile_reset(void);
+int rg_profile_collect(double* ms, double* flops, double* bytes, long long* calls); /* synchronises events */
+
+/* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------
+ * Replaces nn.Conv2d / nn.ConvTranspose2d of the ResNet-50 trunk (CC/clustercontrast/models/
+ * resnet_ibn_a.py:70-159, FD/reid/models/resnet.py:65-75), CustomPoseGenerator
+ * (FD/fdgan/networks.py:86-138) and NLayerDiscriminator (FD/fdgan/networks.py:206-232), and
+ * nn.Linear / Tensor.mm (FD/reid/models/embedding.py:21-24, CC/clustercontrast/models/cm.py:16,26)
+ * as 1x1 geometry.
+ * Geometry: x[N][C][H][W], w[K][C][KH][KW], y[N][K][P][Q]; y = act(conv(x,w)*scale[k] + shift[k] + residual).
+ * scale/shift/residual may be NULL. dgrad computes dx from dy (== ConvTranspose2d forward with
+ * dy as its input and dx[N][C][H][W] as its output; epilogue indexed by c). Stride <= 2 for dgrad.
+ */
+int rg_conv2d_fwd(const float* x, const float* w, float* y, int N, int C, int H, int W, int K, int KH, int KW, int SH,
+                  int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift, const float* residual,
+                  int act, float slope, rg_stream_t stream);
+int rg_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W, int K, int KH, int KW,
+                    int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
+                    const float* residual, int act, float slope, rg_stream_t stream);
+size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
+int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
+                    int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,
+                    rg_stream_t stream);
+
+/* ---- BatchNorm 1d/2d on [N][C][HW] ------------------------------------------------------------
+ * Replaces nn.BatchNorm2d/1d (FD/fdgan/networks.py:26-35; resnet_ibn_a.py:75-81; FD/reid/models/
+ * embedding.py:16-19; CC/clustercontrast/models/resnet.py:58-66). `stat` is invstd (train, from
+ * rg_bn_stats) or the running variance when stat_is_var != 0 (eval). The apply kernels fuse an
+ * optional residual add and activation; the backward takes the forward OUTPUT for the mask. */
+size_t rg_bn_workspace(int N, int C, int HW);
+int rg_bn_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var, int N, int C,
+                int HW, float eps, float momentum, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+int rg_bn_apply_fwd(const float* x, const float* mean, const float* stat, const float* gamma, const float* beta,
+                    const float* residual, float* y, int N, int C, int HW, int stat_is_var, float eps, int act,
+                    float slope, rg_stream_t stream);
+int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
+                     float* sum_dy, float* sum_dy_xhat, int N, int C, int HW, int stat_is_var, float eps, int act,
+                     float slope, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
+                    const float* gamma, const float* sum_dy, const float* sum_dy_xhat, float* dx, float* dres, int N,
+                    int C, int HW, int train, int stat_is_var, float eps, int act, float slope, rg_stream_t stream);
+
+/* ---- element-wise --------------------------------------------------------------------------- */
+int rg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, rg_stream_t stream);
+int rg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, rg_stream_t stream);
+int rg_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, rg_stream_t stream);
+int rg_fill(float* y, int64_t n, float v, rg_stream_t stream);
+/* (x1-x2)^2 of EltwiseSubEmbed, FD/reid/models/embedding.py:26-31 */
+int rg_sub_square_fwd(const float* a, const float* b, float* y, int64_t n, rg_stream_t stream);
+int rg_sub_square_bwd(const float* a, const float* b, const float* dy, float* da, float* db, int64_t n,
+                      rg_stream_t stream);
+/* nn.Dropout of the generator decoder, FD/fdgan/networks.py:105-109,149-156; counter-based mask */
+int rg_dropout(const float* x, float* y, int64_t n, float p, unsigned long long seed, rg_stream_t stream);
+/* F.normalize(x, dim=1) on [rows][D], CC/clustercontrast/models/cm.py:125, resnet.py:90-107 */
+int rg_l2norm_rows_fwd(const float* x, float* y, float* norm, int rows, int D, float eps, rg_stream_t stream);
+int rg_l2norm_rows_bwd(const float* y, const float* dy, const float* norm, float* dx, int rows, int D, float eps,
+                       rg_stream_t stream);
+/* torch.cat along channels / its backward slices, FD/fdgan/model.py:160-161, networks.py:175 */
+int rg_copy_channels(const float* src, float* dst, int N, int Cc, int HW, int Cs, int sc0, int Cd, int dc0,
+                     int accumulate, rg_stream_t stream);
+
+/* ---- pooling -------------------------------------------------------------------------------- */
+int rg_maxpool2d_fwd(const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W, int KH, int KW,
+                     int SH, int SW, int PH, int PW, int P, int Q, rg_stream_t stream);
+int rg_maxpool2d_bwd(const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W, int KH,
+                     int KW, int SH, int SW, int PH, int PW, int P, int Q, rg_stream_t stream);
+/* F.avg_pool2d(x, x.size()[2:]), FD/reid/models/resnet.py:71 */
+int rg_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, rg_stream_t stream);
+int rg_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, rg_stream_t stream);
+/* GeneralizedMeanPoolingP, CC/clustercontrast/models/pooling.py:57-103 */
+int rg_gem_pool_fwd(const float* x, const float* p, float* y, int N, int C, int HW, float eps, rg_stream_t stream);
+int rg_gem_pool_bwd(const float* x, const float* p, const float* y, const float* dy, float* dx, float* dp, int N,
+                    int C, int HW, float eps, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+
+/* ---- losses (scalar outputs live in device memory; grad_out is a 1-element device tensor or NULL) */
+size_t rg_loss_workspace(void);
+/* GANLoss: sigmoid + BCE vs constant target, FD/fdgan/losses.py:29-32 */
+int rg_sigmoid_bce_fwd(const float* x, float* loss, int64_t n, float target, void* workspace, size_t workspace_bytes,
+                       rg_stream_t stream);
+int rg_sigmoid_bce_bwd(const float* x, const float* grad_out, float* dx, int64_t n, float target, float grad_scale,
+                       rg_stream_t stream);
+/* lsgan: MSE vs constant label, CC/dual_gan/models/external_function.py:53-57 */
+int rg_mse_const_fwd(const float* x, float* loss, int64_t n, float target, void* workspace, size_t workspace_bytes,
+                     rg_stream_t stream);
+int rg_mse_const_bwd(const float* x, const float* grad_out, float* dx, int64_t n, float target, float grad_scale,
+                     rg_stream_t stream);
+/* F.l1_loss, optionally over the rows with row_labels == 1 (same-identity pairs), FD/fdgan/model.py:190-194.
+ * out2[0] = loss, out2[1] = 1/(number of selected elements). */
+int rg_l1_fwd(const float* a, const float* b, const int64_t* row_labels, float* out2, int rows, int64_t inner,
+              void* workspace, size_t workspace_bytes, rg_stream_t stream);
+int rg_l1_bwd(const float* a, const float* b, const int64_t* row_labels, const float* grad_out, const float* out2,
+              float* da, float* db, int rows, int64_t inner, float grad_scale, rg_stream_t stream);
+/* F.cross_entropy(scale*logits, labels, reduction='none'), FD/fdgan/model.py:189, CC/.../cm.py:134-135 */
+int rg_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_rows, float* lse, int B, int K,
+                      float scale, rg_stream_t stream);
+int rg_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* grad_rows,
+                      float* dlogits, int B, int K, float scale, float grad_scale, rg_stream_t stream);
+/* out[0] = scale * sum_i x[i]*w[i] (w may be NULL): .mean() / conf_mask weighting of per-sample losses */
+int rg_weighted_sum_fwd(const float* x, const float* w, float* out, int64_t n, float scale, rg_stream_t stream);
+int rg_weighted_sum_bwd(const float* grad_out, const float* w, float* dx, int64_t n, float scale, rg_stream_t stream);
+
+/* ---- ClusterMemory momentum update, CC/clustercontrast/models/cm.py:29-31 (CM), :57-70 (CM_Hard),
+ * :100-104 (CM_gan second bank: normalize_eps = 1).  In place on features[K][D], batch order kept. */
+int rg_cm_update(const float* inputs, const int64_t* targets, float* features, int B, int D, int K, float momentum,
+                 int normalize_eps, rg_stream_t stream);
+int rg_cm_update_hard(const float* inputs, const int64_t* targets, float* features, int B, int D, int K,
+                      float momentum, rg_stream_t stream);
+
+/* ---- fused optimizer steps on contiguous ranges (FD/fdgan/model.py:100-125; CC/examples/
+ * cluster_contrast_gan_train_usl_infomap.py:281-284). grad_scale multiplies g first (1/world for DDP). */
+int rg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, float grad_scale, rg_stream_t stream);
+int rg_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                float weight_decay, int first_step, float grad_scale, rg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REIDGAN_HIP_H */

@@ -1,0 +1,413 @@
+// BatchNorm (1d/2d, train and eval) for gfx950 — HBM-bound kernels: coalesced float4 streams,
+// wave-shuffle (Chan) merges for the statistics, one read + one write per activation element.
+//
+// Replaces torch.nn.BatchNorm2d / BatchNorm1d as used by
+//   ResNet-50 bottlenecks       CC/clustercontrast/models/resnet_ibn_a.py:70-109 (train mode in cluster-contrast,
+//                               eval mode with trainable affine in FD-GAN: FD/fdgan/model.py:72-85, networks.py:57-60)
+//   CustomPoseGenerator / NLayerDiscriminator norm layers   FD/fdgan/networks.py:26-35,141-156,218-229
+//   EltwiseSubEmbed.bn, feat_bn                              FD/reid/models/embedding.py:16-19, CC/.../resnet.py:58-66
+// Semantics follow torch: biased variance for normalisation, unbiased for running_var,
+// running = (1-momentum)*running + momentum*batch.
+//
+// Tensor layout: [N][C][HW] contiguous (HW = 1 for BatchNorm1d on [N][C]).
+#include "rg_common.h"
+
+namespace {
+
+struct WStat {
+    float n, mean, m2;
+};
+
+__device__ __forceinline__ WStat chan_merge(WStat a, WStat b) {
+    WStat r;
+    r.n = a.n + b.n;
+    if (r.n == 0.f) {
+        r.mean = 0.f;
+        r.m2 = 0.f;
+        return r;
+    }
+    const float d = b.mean - a.mean;
+    const float f = b.n / r.n;
+    r.mean = a.mean + d * f;
+    r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+    return r;
+}
+
+__device__ __forceinline__ WStat wave_merge(WStat s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        WStat o;
+        o.n = __shfl_xor(s.n, off, 64);
+        o.mean = __shfl_xor(s.mean, off, 64);
+        o.m2 = __shfl_xor(s.m2, off, 64);
+        s = chan_merge(s, o);
+    }
+    return s;
+}
+
+// grid (S, C): block (s, c) reduces elements [s*L, (s+1)*L) of channel c's N*HW values.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                               int N, int C, int HW, int L) {
+    const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const int64_t total = (int64_t)N * HW;
+    const int64_t beg = (int64_t)s * L;
+    int64_t end = beg + L;
+    if (end > total) end = total;
+    float shift = 0.f, sum = 0.f, sq = 0.f, cnt = 0.f;
+    bool first = true;
+    if ((HW & 3) == 0) {
+        for (int64_t e = beg + (int64_t)threadIdx.x * 4; e < end; e += 256 * 4) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)n * C + c) * HW + hw);
+            if (first) {
+                shift = v.x;
+                first = false;
+            }
+            const float a = v.x - shift, b = v.y - shift, cc = v.z - shift, d = v.w - shift;
+            sum += (a + b) + (cc + d);
+            sq += (a * a + b * b) + (cc * cc + d * d);
+            cnt += 4.f;
+        }
+    } else {
+        for (int64_t e = beg + threadIdx.x; e < end; e += 256) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const float v = x[((int64_t)n * C + c) * HW + hw];
+            if (first) {
+                shift = v;
+                first = false;
+            }
+            const float a = v - shift;
+            sum += a;
+            sq += a * a;
+            cnt += 1.f;
+        }
+    }
+    WStat st;
+    st.n = cnt;
+    st.mean = cnt > 0.f ? shift + sum / cnt : 0.f;
+    st.m2 = cnt > 0.f ? fmaxf(sq - sum * sum / cnt, 0.f) : 0.f;
+    st = wave_merge(st);
+    __shared__ WStat red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[wid] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        WStat t = red[0];
+        for (int i = 1; i < 4; ++i) t = chan_merge(t, red[i]);
+        float* o = part + ((int64_t)c * S + s) * 3;
+        o[0] = t.n;
+        o[1] = t.mean;
+        o[2] = t.m2;
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int C, int S, float eps, float momentum,
+                                         float* __restrict__ mean, float* __restrict__ invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    WStat t;
+    t.n = 0.f;
+    t.mean = 0.f;
+    t.m2 = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* o = part + ((int64_t)c * S + s) * 3;
+        WStat b;
+        b.n = o[0];
+        b.mean = o[1];
+        b.m2 = o[2];
+        t = chan_merge(t, b);
+    }
+    const float var = t.n > 0.f ? t.m2 / t.n : 0.f;
+    mean[c] = t.mean;
+    invstd[c] = rsqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * t.mean;
+    if (running_var) {
+        const float unb = t.n > 1.f ? t.m2 / (t.n - 1.f) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
+// y = act((x - mean[c]) * invstd[c] * gamma[c] + beta[c] + res)
+// stat_is_var: `invstd` holds a variance (eval mode: running_var) and eps is applied here.
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, int64_t total, int C, int HW,
+                                                           int stat_is_var, float eps, int act, float slope) {
+    if ((HW & 3) == 0) {
+        const int64_t nv = total >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t e = i << 2;
+            const int c = (int)((e / HW) % C);
+            float is = invstd[c];
+            if (stat_is_var) is = rsqrtf(is + eps);
+            const float sc = is * (gamma ? gamma[c] : 1.f);
+            const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+            float4 v = *reinterpret_cast<const float4*>(x + e);
+            v.x = v.x * sc + sh;
+            v.y = v.y * sc + sh;
+            v.z = v.z * sc + sh;
+            v.w = v.w * sc + sh;
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(res + e);
+                v.x += r.x;
+                v.y += r.y;
+                v.z += r.z;
+                v.w += r.w;
+            }
+            v.x = rg_apply_act(v.x, act, slope);
+            v.y = rg_apply_act(v.y, act, slope);
+            v.z = rg_apply_act(v.z, act, slope);
+            v.w = rg_apply_act(v.w, act, slope);
+            *reinterpret_cast<float4*>(y + e) = v;
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+            const int c = (int)((e / HW) % C);
+            float is = invstd[c];
+            if (stat_is_var) is = rsqrtf(is + eps);
+            const float sc = is * (gamma ? gamma[c] : 1.f);
+            const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+            float v = x[e] * sc + sh;
+            if (res) v += res[e];
+            y[e] = rg_apply_act(v, act, slope);
+        }
+    }
+}
+
+__device__ __forceinline__ float act_grad_from_out(float yv, int act, float slope) {
+    switch (act) {
+        case RG_ACT_RELU: return yv > 0.f ? 1.f : 0.f;
+        case RG_ACT_LEAKY: return yv > 0.f ? 1.f : slope;
+        case RG_ACT_TANH: return 1.f - yv * yv;
+        default: return 1.f;
+    }
+}
+
+// partial sums over a slice: sum(dy_eff), sum(dy_eff * xhat); dy_eff = dy * act'(y)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_partial_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ dy,
+                                                                    const float* __restrict__ yact,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    float* __restrict__ part, int N, int C, int HW,
+                                                                    int L, int stat_is_var, float eps, int act,
+                                                                    float slope) {
+    const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const int64_t total = (int64_t)N * HW;
+    const int64_t beg = (int64_t)s * L;
+    int64_t end = beg + L;
+    if (end > total) end = total;
+    const float mu = mean[c];
+    float is = invstd[c];
+    if (stat_is_var) is = rsqrtf(is + eps);
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+        for (int64_t e = beg + (int64_t)threadIdx.x * 4; e < end; e += 256 * 4) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            const float4 xv = *reinterpret_cast<const float4*>(x + o);
+            float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (act != RG_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(yact + o);
+                g.x *= act_grad_from_out(yv.x, act, slope);
+                g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope);
+                g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+        }
+    } else {
+        for (int64_t e = beg + threadIdx.x; e < end; e += 256) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            float g = dy[o];
+            if (act != RG_ACT_NONE) g *= act_grad_from_out(yact[o], act, slope);
+            s1 += g;
+            s2 += g * (x[o] - mu);
+        }
+    }
+    s2 *= is;
+    __shared__ float red[16];
+    s1 = rg_block_sum(s1, red);
+    s2 = rg_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((int64_t)c * S + s) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+
+__global__ void bn_bwd_reduce_finalize_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ sum_dy,
+                                              float* __restrict__ sum_dy_xhat) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) {
+        a += part[((int64_t)c * S + s) * 2 + 0];
+        b += part[((int64_t)c * S + s) * 2 + 1];
+    }
+    sum_dy[c] = a;
+    sum_dy_xhat[c] = b;
+}
+
+// dx = gamma*invstd * (g - train*(sum_dy/cnt + xhat*sum_dy_xhat/cnt)),  g = dy*act'(y);  dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ yact,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sum_dy,
+                                                           const float* __restrict__ sum_dy_xhat,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           int64_t total, int C, int HW, float inv_count, int train,
+                                                           int stat_is_var, float eps, int act, float slope) {
+    const bool vec = (HW & 3) == 0;
+    const int64_t nitems = vec ? (total >> 2) : total;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nitems; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = vec ? (i << 2) : i;
+        const int c = (int)((e / HW) % C);
+        const float mu = mean[c];
+        float is = invstd[c];
+        if (stat_is_var) is = rsqrtf(is + eps);
+        const float gs = (gamma ? gamma[c] : 1.f) * is;
+        const float a = train ? sum_dy[c] * inv_count : 0.f;
+        const float b = train ? sum_dy_xhat[c] * inv_count : 0.f;
+        if (vec) {
+            float4 g = *reinterpret_cast<const float4*>(dy + e);
+            if (act != RG_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(yact + e);
+                g.x *= act_grad_from_out(yv.x, act, slope);
+                g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope);
+                g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (dres) *reinterpret_cast<float4*>(dres + e) = g;
+            if (dx) {
+                float4 o;
+                if (train) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + e);
+                    o.x = gs * (g.x - a - (xv.x - mu) * is * b);
+                    o.y = gs * (g.y - a - (xv.y - mu) * is * b);
+                    o.z = gs * (g.z - a - (xv.z - mu) * is * b);
+                    o.w = gs * (g.w - a - (xv.w - mu) * is * b);
+                } else {
+                    o.x = gs * g.x;
+                    o.y = gs * g.y;
+                    o.z = gs * g.z;
+                    o.w = gs * g.w;
+                }
+                *reinterpret_cast<float4*>(dx + e) = o;
+            }
+        } else {
+            float g = dy[e];
+            if (act != RG_ACT_NONE) g *= act_grad_from_out(yact[e], act, slope);
+            if (dres) dres[e] = g;
+            if (dx) dx[e] = train ? gs * (g - a - (x[e] - mu) * is * b) : gs * g;
+        }
+    }
+}
+
+static int pick_slices(int N, int C, int HW, int* L) {
+    const int64_t total = (int64_t)N * HW;
+    int64_t S = rg::cdiv(2048, C);
+    const int64_t maxS = rg::cdiv64(total, 4096);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    int64_t l = rg::cdiv64(total, S);
+    l = (l + 3) & ~3ll;
+    *L = (int)l;
+    return (int)rg::cdiv64(total, l);
+}
+
+static unsigned grid_for(int64_t items) {
+    int64_t g = rg::cdiv64(items, 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" size_t rg_bn_workspace(int N, int C, int HW) {
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    return (size_t)C * S * 3 * sizeof(float);
+}
+
+// Batch statistics of x[N][C][HW]: mean[C], invstd[C] (=1/sqrt(biased var + eps)); updates the
+// running statistics in place when they are given.
+extern "C" int rg_bn_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var, int N,
+                           int C, int HW, float eps, float momentum, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
+    RG_REQUIRE(x && mean && invstd && N > 0 && C > 0 && HW > 0, "rg_bn_stats: bad arguments");
+    RG_REQUIRE((int64_t)N * HW < (1ll << 31), "rg_bn_stats: N*HW exceeds 2^31");
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    if (!workspace || workspace_bytes < (size_t)C * S * 3 * sizeof(float)) {
+        rg::set_error("rg_bn_stats: workspace too small");
+        return RG_ERR_WORKSPACE;
+    }
+    float* part = static_cast<float*>(workspace);
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * N * (double)C * HW);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(S, C), dim3(256), 0, stream, x, part, N, C, HW, L);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, part, C, S, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    return rg::check_launch("rg_bn_stats");
+}
+
+extern "C" int rg_bn_apply_fwd(const float* x, const float* mean, const float* stat, const float* gamma,
+                               const float* beta, const float* residual, float* y, int N, int C, int HW,
+                               int stat_is_var, float eps, int act, float slope, hipStream_t stream) {
+    RG_REQUIRE(x && mean && stat && y && N > 0 && C > 0 && HW > 0, "rg_bn_apply_fwd: bad arguments");
+    const int64_t total = (int64_t)N * C * HW;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * total);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for((HW & 3) ? total : total / 4)), dim3(256), 0, stream, x, mean,
+                       stat, gamma, beta, residual, y, total, C, HW, stat_is_var, eps, act, slope);
+    return rg::check_launch("rg_bn_apply_fwd");
+}
+
+// Per-channel sums for the affine gradients: dbeta = sum(dy*act'(y)), dgamma = sum(dy*act'(y)*xhat).
+extern "C" int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const float* mean,
+                                const float* stat, float* sum_dy, float* sum_dy_xhat, int N, int C, int HW,
+                                int stat_is_var, float eps, int act, float slope, void* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
+    RG_REQUIRE(x && dy && mean && stat && sum_dy && sum_dy_xhat, "rg_bn_bwd_reduce: null tensor");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_bn_bwd_reduce: fused activation needs the forward output");
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    if (!workspace || workspace_bytes < (size_t)C * S * 2 * sizeof(float)) {
+        rg::set_error("rg_bn_bwd_reduce: workspace too small");
+        return RG_ERR_WORKSPACE;
+    }
+    float* part = static_cast<float*>(workspace);
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (act ? 12.0 : 8.0) * N * (double)C * HW);
+    hipLaunchKernelGGL(bn_bwd_reduce_partial_kernel, dim3(S, C), dim3(256), 0, stream, x, dy, y_act, mean, stat, part, N,
+                       C, HW, L, stat_is_var, eps, act, slope);
+    hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, part, C, S, sum_dy,
+                       sum_dy_xhat);
+    return rg::check_launch("rg_bn_bwd_reduce");
+}
+
+// dx (may be NULL) and dres (may be NULL; the gradient of a fused residual input = dy*act'(y)).
+extern "C" int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_act, const float* mean,
+                               const float* stat, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
+                               float* dx, float* dres, int N, int C, int HW, int train, int stat_is_var, float eps,
+                               int act, float slope, hipStream_t stream) {
+    RG_REQUIRE(dy && mean && stat && (dx || dres), "rg_bn_bwd_apply: null tensor");
+    RG_REQUIRE(!train || (x && sum_dy && sum_dy_xhat), "rg_bn_bwd_apply: train mode needs x and the channel sums");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_bn_bwd_apply: fused activation needs the forward output");
+    const int64_t total = (int64_t)N * C * HW;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 16.0 * total);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((HW & 3) ? total : total / 4)), dim3(256), 0, stream, x, dy,
+                       y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, dx, dres, total, C, HW,
+                       1.f / (float)((int64_t)N * HW), train, stat_is_var, eps, act, slope);
+    return rg::check_launch("rg_bn_bwd_apply");
+}

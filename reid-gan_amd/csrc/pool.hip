@@ -1,0 +1,219 @@
+// Pooling kernels for the ResNet trunks (HBM-bound).
+//   max-pool 3x3/2 pad 1 after the stem           CC/clustercontrast/models/resnet_ibn_a.py:121 (torchvision layout)
+//   global average pool (F.avg_pool2d full map)   FD/reid/models/resnet.py:71-72
+//   GeM pooling, learnable p                      CC/clustercontrast/models/pooling.py:57-103
+#include "rg_common.h"
+
+namespace {
+
+static unsigned grid_for(int64_t items) {
+    int64_t g = rg::cdiv64(items, 256);
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// y[n,c,p,q] = max over the window; arg = window-local index (r*KW+s) of the FIRST maximum in scan
+// order (torch semantics), NaN propagates like torch (a NaN wins).
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ arg,
+                                   int64_t total, int H, int W, int P, int Q, int KH, int KW, int SH, int SW, int PH,
+                                   int PW) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        const int64_t t = i / Q;
+        const int p = (int)(t % P);
+        const int64_t plane = t / P;
+        const float* xp = x + plane * H * W;
+        const int h0 = p * SH - PH, w0 = q * SW - PW;
+        float best = -INFINITY;
+        int bi = -1;
+        for (int r = 0; r < KH; ++r) {
+            const int h = h0 + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int s = 0; s < KW; ++s) {
+                const int w = w0 + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const float v = xp[h * W + w];
+                if (bi < 0) bi = r * KW + s;  // torch starts at the first in-bounds element
+                if (v > best || (v != v)) {
+                    best = v;
+                    bi = r * KW + s;
+                }
+            }
+        }
+        y[i] = best;
+        arg[i] = (unsigned char)bi;
+    }
+}
+
+// gather form (no atomics, deterministic): each input pixel sums dy of the windows that selected it
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                   float* __restrict__ dx, int64_t total, int H, int W, int P, int Q, int KH, int KW,
+                                   int SH, int SW, int PH, int PW) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int64_t t = i / W;
+        const int h = (int)(t % H);
+        const int64_t plane = t / H;
+        const float* gp = dy + plane * P * Q;
+        const unsigned char* ap = arg + plane * P * Q;
+        float acc = 0.f;
+        // windows p with p*SH - PH <= h <= p*SH - PH + KH - 1
+        int p_lo = (h + PH - KH + 1 + SH - 1);
+        p_lo = p_lo > 0 ? p_lo / SH : 0;
+        int p_hi = (h + PH) / SH;
+        if (p_hi > P - 1) p_hi = P - 1;
+        int q_lo = (w + PW - KW + 1 + SW - 1);
+        q_lo = q_lo > 0 ? q_lo / SW : 0;
+        int q_hi = (w + PW) / SW;
+        if (q_hi > Q - 1) q_hi = Q - 1;
+        for (int p = p_lo; p <= p_hi; ++p) {
+            const int r = h - (p * SH - PH);
+            for (int q = q_lo; q <= q_hi; ++q) {
+                const int s = w - (q * SW - PW);
+                if (ap[p * Q + q] == (unsigned char)(r * KW + s)) acc += gp[p * Q + q];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// one wave per (n,c) plane
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int planes,
+                                                      int HW) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const float* xp = x + (int64_t)plane * HW;
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += xp[i];
+    s = rg_wave_sum(s);
+    if (lane == 0) y[plane] = s / (float)HW;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t total, int HW) {
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i / HW] * inv;
+}
+
+// GeM: y = (mean(clamp(x, eps)^p))^(1/p); one wave per plane.
+__global__ __launch_bounds__(256) void gem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pp,
+                                                      float* __restrict__ y, int planes, int HW, float eps) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const float p = pp[0];
+    const float* xp = x + (int64_t)plane * HW;
+    float s = 0.f;
+    for (int i = lane; i < HW; i += 64) s += powf(fmaxf(xp[i], eps), p);
+    s = rg_wave_sum(s);
+    if (lane == 0) y[plane] = powf(s / (float)HW, 1.f / p);
+}
+
+// dx = dy * m^(1/p - 1) * xc^(p-1) / HW * [x >= eps]
+// dp_part[plane] = dy * y * ( -log(m)/p^2 + (1/p) * mean(xc^p log xc) / m )
+__global__ __launch_bounds__(256) void gem_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pp,
+                                                      const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, float* __restrict__ dp_part, int planes,
+                                                      int HW, float eps) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const float p = pp[0];
+    const float* xp = x + (int64_t)plane * HW;
+    float* dp_ = dx + (int64_t)plane * HW;
+    const float yv = y[plane], g = dy[plane];
+    const float m = powf(yv, p);  // mean(xc^p)
+    const float coef = g * yv / (m * (float)HW);  // g * m^(1/p-1) / HW
+    float sl = 0.f;
+    for (int i = lane; i < HW; i += 64) {
+        const float xv = xp[i];
+        const float xc = fmaxf(xv, eps);
+        const float xpw = powf(xc, p - 1.f);
+        dp_[i] = xv >= eps ? coef * xpw : 0.f;
+        sl += xpw * xc * logf(xc);
+    }
+    sl = rg_wave_sum(sl);
+    if (lane == 0 && dp_part) {
+        const float mean_l = sl / (float)HW;
+        dp_part[plane] = g * yv * (-logf(m) / (p * p) + mean_l / (p * m));
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = rg_block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+}  // namespace
+
+extern "C" int rg_maxpool2d_fwd(const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W, int KH,
+                                int KW, int SH, int SW, int PH, int PW, int P, int Q, hipStream_t stream) {
+    RG_REQUIRE(x && y && argmax && N > 0 && C > 0 && H > 0 && W > 0 && P > 0 && Q > 0, "rg_maxpool2d_fwd: bad arguments");
+    RG_REQUIRE(KH * KW <= 255 && PH < KH && PW < KW, "rg_maxpool2d_fwd: unsupported window");
+    const int64_t total = (int64_t)N * C * P * Q;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * N * C * ((double)H * W + 1.25 * P * Q));
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, argmax, total, H, W, P, Q,
+                       KH, KW, SH, SW, PH, PW);
+    return rg::check_launch("rg_maxpool2d_fwd");
+}
+
+extern "C" int rg_maxpool2d_bwd(const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
+                                int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, hipStream_t stream) {
+    RG_REQUIRE(dy && dx && argmax && N > 0 && C > 0, "rg_maxpool2d_bwd: bad arguments");
+    const int64_t total = (int64_t)N * C * H * W;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * N * C * ((double)H * W + 1.25 * P * Q));
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, argmax, dx, total, H, W, P,
+                       Q, KH, KW, SH, SW, PH, PW);
+    return rg::check_launch("rg_maxpool2d_bwd");
+}
+
+extern "C" int rg_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, hipStream_t stream) {
+    RG_REQUIRE(x && y && N > 0 && C > 0 && HW > 0, "rg_global_avgpool_fwd: bad arguments");
+    const int planes = N * C;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * planes * (double)HW);
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(rg::cdiv(planes, 4)), dim3(256), 0, stream, x, y, planes, HW);
+    return rg::check_launch("rg_global_avgpool_fwd");
+}
+
+extern "C" int rg_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, hipStream_t stream) {
+    RG_REQUIRE(dy && dx && N > 0 && C > 0 && HW > 0, "rg_global_avgpool_bwd: bad arguments");
+    const int64_t total = (int64_t)N * C * HW;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * total);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, total, HW);
+    return rg::check_launch("rg_global_avgpool_bwd");
+}
+
+extern "C" int rg_gem_pool_fwd(const float* x, const float* p, float* y, int N, int C, int HW, float eps,
+                               hipStream_t stream) {
+    RG_REQUIRE(x && p && y && N > 0 && C > 0 && HW > 0, "rg_gem_pool_fwd: bad arguments");
+    const int planes = N * C;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * planes * (double)HW);
+    hipLaunchKernelGGL(gem_fwd_kernel, dim3(rg::cdiv(planes, 4)), dim3(256), 0, stream, x, p, y, planes, HW, eps);
+    return rg::check_launch("rg_gem_pool_fwd");
+}
+
+// workspace: N*C floats (per-plane dp partials).  dp (1 element) may be NULL.
+extern "C" int rg_gem_pool_bwd(const float* x, const float* p, const float* y, const float* dy, float* dx, float* dp,
+                               int N, int C, int HW, float eps, void* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
+    RG_REQUIRE(x && p && y && dy && dx && N > 0 && C > 0 && HW > 0, "rg_gem_pool_bwd: bad arguments");
+    const int planes = N * C;
+    float* part = nullptr;
+    if (dp) {
+        if (!workspace || workspace_bytes < (size_t)planes * sizeof(float)) {
+            rg::set_error("rg_gem_pool_bwd: workspace too small");
+            return RG_ERR_WORKSPACE;
+        }
+        part = static_cast<float*>(workspace);
+    }
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 8.0 * planes * (double)HW);
+    hipLaunchKernelGGL(gem_bwd_kernel, dim3(rg::cdiv(planes, 4)), dim3(256), 0, stream, x, p, y, dy, dx, part, planes, HW,
+                       eps);
+    if (dp) hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, part, dp, (int64_t)planes);
+    return rg::check_launch("rg_gem_pool_bwd");
+}

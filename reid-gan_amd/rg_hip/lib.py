@@ -1,0 +1,121 @@
+"""ctypes binding of libreidgan_hip.so (the C ABI declared in include/reidgan_hip.h).
+
+The prototypes are parsed from the header itself, so the header is the single source of truth for
+the boundary.  There is NO fallback: if the shared library is missing or a call fails, this module
+raises — the product path never silently runs anything else.
+"""
+from __future__ import absolute_import
+
+import ctypes
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                      # reid-gan_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libreidgan_hip.so")
+HEADER_PATH = os.path.join(REPO_ROOT, "include", "reidgan_hip.h")
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "int64_t": ctypes.c_int64,
+    "size_t": ctypes.c_size_t,
+    "unsigned long long": ctypes.c_ulonglong,
+    "rg_stream_t": ctypes.c_void_p,
+    "void": None,
+    "const char*": ctypes.c_char_p,
+}
+
+
+def _ctype_of(decl):
+    decl = decl.strip()
+    if decl.endswith("*"):
+        if decl == "const char*":
+            return ctypes.c_char_p
+        return ctypes.c_void_p          # every device/host buffer crosses as an opaque address
+    return _CTYPES[decl]
+
+
+def parse_header(path=HEADER_PATH):
+    """Returns {name: (restype_decl, [(type_decl, arg_name), ...])} for every prototype."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(rg_\w+)\s*\(([^;{}]*?)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        ret = re.sub(r"\s*\*", "*", ret)
+        parsed = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                tdecl = re.sub(r"\s*\*\s*", "*", mm.group(1).strip())
+                parsed.append((tdecl, mm.group(2)))
+        protos[name] = (ret, parsed)
+    return protos
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into reid-gan_amd/lib/libreidgan_hip.so (in-tree)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libreidgan_hip.so failed")
+    return LIB_PATH
+
+
+_PLAIN_INT = {"rg_version", "rg_family_count"}   # int-returning queries that are not status codes
+
+
+class _Lib(object):
+    def __init__(self):
+        self._dll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._dll is not None:
+            return self
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libreidgan_hip.so not found at %s — build it with `make -C %s` or __graft_entry__.build(); "
+                "there is no CPU / PyTorch fallback for the HIP path" % (LIB_PATH, CSRC_DIR))
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(dll, name)            # AttributeError if the header and library disagree
+            fn.restype = _ctype_of(ret) if ret != "void" else None
+            fn.argtypes = [_ctype_of(t) for t, _ in args]
+        self._dll = dll
+        return self
+
+    def __getattr__(self, name):
+        if name.startswith("rg_"):
+            self.load()
+            raw = getattr(self._dll, name)
+            ret = self.protos[name][0]
+            if ret != "int" or name in _PLAIN_INT:
+                return raw
+            dll = self._dll
+
+            def checked(*args):
+                st = raw(*args)
+                if st != 0:
+                    raise RuntimeError("%s failed (%d): %s" % (name, st, dll.rg_last_error().decode()))
+                return st
+            checked.__name__ = name
+            setattr(self, name, checked)      # cache
+            return checked
+        raise AttributeError(name)
+
+
+lib = _Lib()
+
+FAMILIES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "norm", "eltwise", "pool", "loss", "cm", "optim", "misc"]

@@ -1,0 +1,294 @@
+"""Layer set of the hot path as RGModules (same constructor arguments, parameter names, default
+initialisation and state_dict layout as the torch.nn layers the reference composes).
+
+Fusion available to the network programs (all exact, no re-association beyond fp32 rounding):
+  Conv2d / ConvTranspose2d : + bias, + activation in the MFMA epilogue
+  BatchNorm               : normalise + affine (+ residual add) (+ activation) in one pass
+"""
+from __future__ import absolute_import
+
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH
+from .tape import RGModule
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+class Conv2d(RGModule):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super(Conv2d, self).__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):          # identical to torch.nn.Conv2d.reset_parameters
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
+
+    def tf(self, tape, x, act=ACT_NONE, slope=0.0):
+        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, act=act, slope=slope)
+        tape.push((x, y if act != ACT_NONE else None, act, slope))
+        return y
+
+    def tb(self, tape, dy, need_dx=True, residual=None):
+        x, y, act, slope = tape.pop()
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
+        if tape.wants(self.weight):
+            tape.add_grad(self.weight, ops.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding))
+        if tape.wants(self.bias):
+            tape.add_grad(self.bias, ops.channel_sum(dy))
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual)
+
+
+class ConvTranspose2d(RGModule):
+    """weight [in][out][kh][kw] as torch; forward is the dgrad kernel, backward-data the forward kernel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super(ConvTranspose2d, self).__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.output_padding = _pair(output_padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):          # identical to torch.nn.ConvTranspose2d (fan_in from dim 1)
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+
+    def out_hw(self, H, W):
+        return ((H - 1) * self.stride[0] - 2 * self.padding[0] + self.kernel_size[0] + self.output_padding[0],
+                (W - 1) * self.stride[1] - 2 * self.padding[1] + self.kernel_size[1] + self.output_padding[1])
+
+    def tf(self, tape, x, act=ACT_NONE, slope=0.0):
+        hw = self.out_hw(x.shape[2], x.shape[3])
+        y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, act=act, slope=slope)
+        tape.push((x, y if act != ACT_NONE else None, act, slope))
+        return y
+
+    def tb(self, tape, dy, need_dx=True, residual=None):
+        x, y, act, slope = tape.pop()
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
+        if tape.wants(self.weight):
+            tape.add_grad(self.weight, ops.conv2d_wgrad(dy, x, self.weight.shape, self.stride, self.padding))
+        if tape.wants(self.bias):
+            tape.add_grad(self.bias, ops.channel_sum(dy))
+        if not need_dx:
+            return None
+        return ops.conv2d_fwd(dy, self.weight, self.stride, self.padding, residual=residual)
+
+
+class Linear(RGModule):
+    def __init__(self, in_features, out_features, bias=True):
+        super(Linear, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features)
+            init.uniform_(self.bias, -bound, bound)
+
+    def tf(self, tape, x):
+        tape.push(x)
+        return ops.linear_fwd(x, self.weight, self.bias)
+
+    def tb(self, tape, dy, need_dx=True):
+        x = tape.pop()
+        if tape.wants(self.weight):
+            tape.add_grad(self.weight, ops.linear_wgrad(x, dy))
+        if tape.wants(self.bias):
+            tape.add_grad(self.bias, ops.channel_sum(dy))
+        return ops.linear_dgrad(dy, self.weight) if need_dx else None
+
+
+class _BatchNorm(RGModule):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super(_BatchNorm, self).__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        if track_running_stats:
+            self.register_buffer("running_mean", torch.zeros(num_features))
+            self.register_buffer("running_var", torch.ones(num_features))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        else:
+            self.register_buffer("running_mean", None)
+            self.register_buffer("running_var", None)
+            self.register_buffer("num_batches_tracked", None)
+
+    def extra_repr(self):
+        return "%d, eps=%g, momentum=%g, affine=%s" % (self.num_features, self.eps, self.momentum, self.affine)
+
+    def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
+        batch_stats = self.training or not self.track_running_stats
+        if batch_stats:
+            rm = self.running_mean if self.track_running_stats else None
+            rv = self.running_var if self.track_running_stats else None
+            mean, stat = ops.bn_stats(x, rm, rv, self.eps, self.momentum)
+            is_var = False
+            if self.track_running_stats:
+                self.num_batches_tracked += 1          # bookkeeping counter (int64 buffer)
+        else:
+            mean, stat, is_var = self.running_mean, self.running_var, True
+        y = ops.bn_apply_fwd(x, mean, stat, self.weight, self.bias, residual, is_var, self.eps, act, slope)
+        tape.push((x, y if act != ACT_NONE else None, mean, stat, is_var, batch_stats, act, slope, residual is not None))
+        return y
+
+    def tb(self, tape, dy, need_dx=True):
+        x, y, mean, stat, is_var, train, act, slope, has_res = tape.pop()
+        need_affine = tape.wants(self.weight) or tape.wants(self.bias)
+        s1 = s2 = None
+        if need_affine or (train and need_dx):
+            s1, s2 = ops.bn_bwd_reduce(x, dy, y, mean, stat, is_var, self.eps, act, slope)
+            if tape.wants(self.weight):
+                tape.add_grad(self.weight, s2)
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, s1)
+        dx, dres = ops.bn_bwd_apply(x, dy, y, mean, stat, self.weight, s1, s2, train, is_var, self.eps, act, slope,
+                                    need_dx=need_dx or not has_res, need_dres=has_res)
+        return (dx, dres) if has_res else dx
+
+
+class BatchNorm2d(_BatchNorm):
+    pass
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class _Act(RGModule):
+    ACT, SLOPE = ACT_NONE, 0.0
+
+    def __init__(self, *args, **kw):
+        super(_Act, self).__init__()
+
+    def tf(self, tape, x):
+        y = ops.act_fwd(x, self.ACT, self.SLOPE)
+        tape.push(y)
+        return y
+
+    def tb(self, tape, dy, need_dx=True):
+        y = tape.pop()
+        return ops.act_bwd(dy, y, self.ACT, self.SLOPE) if need_dx else None
+
+
+class ReLU(_Act):
+    ACT = ACT_RELU
+
+    def __init__(self, inplace=False):
+        super(ReLU, self).__init__()
+        self.inplace = inplace
+
+
+class LeakyReLU(_Act):
+    ACT = ACT_LEAKY
+
+    def __init__(self, negative_slope=0.01, inplace=False):
+        super(LeakyReLU, self).__init__()
+        self.negative_slope = negative_slope
+        self.SLOPE = negative_slope
+        self.inplace = inplace
+
+
+class Tanh(_Act):
+    ACT = ACT_TANH
+
+
+class Dropout(RGModule):
+    """Inverted dropout with a counter-based mask (seed drawn from torch's CPU generator per call, so
+    torch.manual_seed makes runs reproducible); identity in eval mode or for p == 0."""
+
+    def __init__(self, p=0.5, inplace=False):
+        super(Dropout, self).__init__()
+        self.p = float(p)
+
+    def tf(self, tape, x):
+        if not self.training or self.p == 0.0:
+            tape.push(None)
+            return x
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        tape.push(seed)
+        return ops.dropout(x, self.p, seed)
+
+    def tb(self, tape, dy, need_dx=True):
+        seed = tape.pop()
+        if seed is None or not need_dx:
+            return dy if need_dx else None
+        return ops.dropout(dy, self.p, seed)
+
+
+class MaxPool2d(RGModule):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super(MaxPool2d, self).__init__()
+        self.kernel_size, self.padding = kernel_size, padding
+        self.stride = stride if stride is not None else kernel_size
+
+    def tf(self, tape, x):
+        y, arg = ops.maxpool2d_fwd(x, self.kernel_size, self.stride, self.padding)
+        tape.push((arg, x.shape))
+        return y
+
+    def tb(self, tape, dy, need_dx=True):
+        arg, shape = tape.pop()
+        return ops.maxpool2d_bwd(dy, arg, shape, self.kernel_size, self.stride, self.padding) if need_dx else None
+
+
+class Sequential(RGModule):
+    def __init__(self, *mods):
+        super(Sequential, self).__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def tf(self, tape, x):
+        for m in self._modules.values():
+            x = m.tf(tape, x)
+        return x
+
+    def tb(self, tape, dy, need_dx=True):
+        mods = list(self._modules.values())
+        for i in range(len(mods) - 1, -1, -1):
+            dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
+        return dy

@@ -1,0 +1,521 @@
+"""Tensor-level wrappers over the C ABI: shape logic, output allocation (torch caching allocator),
+stream hand-off.  No autograd here and no arithmetic in torch — every number is produced by a HIP
+kernel of libreidgan_hip.so.  All functions require contiguous fp32 CUDA(HIP) tensors and raise
+otherwise (there is deliberately no CPU path).
+"""
+from __future__ import absolute_import
+
+import torch
+
+from .lib import lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name="tensor", dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("rg_hip: %s must live on the GPU (got %s); the HIP path has no CPU fallback"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("rg_hip: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous() or (t.data_ptr() & 15):
+        t = t.contiguous()
+        if t.data_ptr() & 15:
+            t = t.clone()
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+class _Workspace(object):
+    """One growing scratch buffer per (device, stream); kernels on a stream are ordered, so reuse is safe."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes, device):
+        key = (device.index, _stream())
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+
+
+def workspace(nbytes, device):
+    return _ws.get(nbytes, device)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def conv_out_size(H, W, KH, KW, stride, padding):
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    return (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+
+
+def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0):
+    x, w = _chk(x, "x"), _chk(w, "w")
+    N, C, H, W = x.shape
+    K, Cw, KH, KW = w.shape
+    if C != Cw:
+        raise ValueError("conv2d_fwd: input has %d channels, weight expects %d" % (C, Cw))
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    P, Q = conv_out_size(H, W, KH, KW, (sh, sw), (ph, pw))
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+    scale, shift, residual = _chk(scale, "scale"), _chk(shift, "shift"), _chk(residual, "residual")
+    if residual is not None and residual.shape != y.shape:
+        raise ValueError("conv2d_fwd: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    lib.rg_conv2d_fwd(_p(x), _p(w), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
+                      _p(residual), act, slope, _stream())
+    return y
+
+
+def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0):
+    """dx[N][C][H][W] from dy[N][K][P][Q] and w[K][C][KH][KW]; x_hw = (H, W) of the conv input.
+    Also the forward of ConvTranspose2d (weight [in=K][out=C][KH][KW], output size x_hw)."""
+    dy, w = _chk(dy, "dy"), _chk(w, "w")
+    N, K, P, Q = dy.shape
+    Kw, C, KH, KW = w.shape
+    if K != Kw:
+        raise ValueError("conv2d_dgrad: dy has %d channels, weight expects %d" % (K, Kw))
+    H, W = x_hw
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    scale, shift, residual = _chk(scale, "scale"), _chk(shift, "shift"), _chk(residual, "residual")
+    if residual is not None and residual.shape != dx.shape:
+        raise ValueError("conv2d_dgrad: residual shape mismatch")
+    lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
+                        _p(residual), act, slope, _stream())
+    return dx
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None):
+    x, dy = _chk(x, "x"), _chk(dy, "dy")
+    N, C, H, W = x.shape
+    K, Cw, KH, KW = w_shape
+    Nd, Kd, P, Q = dy.shape
+    if (N, K, C) != (Nd, Kd, Cw):
+        raise ValueError("conv2d_wgrad: inconsistent shapes x=%s dy=%s w=%s" % (tuple(x.shape), tuple(dy.shape), w_shape))
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    nbytes = lib.rg_conv2d_wgrad_workspace(N, C, K, KH, KW, P, Q)
+    ws = workspace(nbytes, x.device)
+    lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
+                        _stream())
+    return dw
+
+
+def linear_fwd(x, w, bias=None):
+    """y[B][out] = x[B][in] @ w[out][in]^T + bias, as a 1x1 conv on a 1x1 map."""
+    B, Cin = x.shape
+    y = conv2d_fwd(x.view(B, Cin, 1, 1), w.view(w.shape[0], Cin, 1, 1), shift=bias)
+    return y.view(B, w.shape[0])
+
+
+def linear_dgrad(dy, w):
+    B, K = dy.shape
+    dx = conv2d_dgrad(dy.view(B, K, 1, 1), w.view(K, w.shape[1], 1, 1), (1, 1))
+    return dx.view(B, w.shape[1])
+
+
+def linear_wgrad(x, dy):
+    B, Cin = x.shape
+    K = dy.shape[1]
+    return conv2d_wgrad(x.view(B, Cin, 1, 1), dy.view(B, K, 1, 1), (K, Cin, 1, 1)).view(K, Cin)
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm on [N][C][HW]
+# ------------------------------------------------------------------------------------------------
+def _nchw(x):
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1], 1
+    N, C = x.shape[0], x.shape[1]
+    return N, C, x.numel() // (N * C)
+
+
+def bn_stats(x, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    x = _chk(x, "x")
+    N, C, HW = _nchw(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.rg_bn_workspace(N, C, HW), x.device)
+    lib.rg_bn_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), N, C, HW, eps, momentum, _p(ws),
+                    ws.numel(), _stream())
+    return mean, invstd
+
+
+def bn_apply_fwd(x, mean, stat, gamma, beta, residual=None, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0):
+    x = _chk(x, "x")
+    residual = _chk(residual, "residual")
+    N, C, HW = _nchw(x)
+    y = torch.empty_like(x)
+    lib.rg_bn_apply_fwd(_p(x), _p(mean), _p(stat), _p(gamma), _p(beta), _p(residual), _p(y), N, C, HW,
+                        int(stat_is_var), eps, act, slope, _stream())
+    return y
+
+
+def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0):
+    x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    N, C, HW = _nchw(x)
+    sum_dy = torch.empty(C, dtype=torch.float32, device=x.device)
+    sum_dy_xhat = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.rg_bn_workspace(N, C, HW), x.device)
+    lib.rg_bn_bwd_reduce(_p(x), _p(dy), _p(y_act), _p(mean), _p(stat), _p(sum_dy), _p(sum_dy_xhat), N, C, HW,
+                         int(stat_is_var), eps, act, slope, _p(ws), ws.numel(), _stream())
+    return sum_dy, sum_dy_xhat
+
+
+def bn_bwd_apply(x, dy, y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, train, stat_is_var=False, eps=1e-5,
+                 act=ACT_NONE, slope=0.0, need_dx=True, need_dres=False):
+    x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    N, C, HW = _nchw(dy)
+    dx = torch.empty_like(dy) if need_dx else None
+    dres = torch.empty_like(dy) if need_dres else None
+    lib.rg_bn_bwd_apply(_p(x), _p(dy), _p(y_act), _p(mean), _p(stat), _p(gamma), _p(sum_dy), _p(sum_dy_xhat), _p(dx),
+                        _p(dres), N, C, HW, int(train), int(stat_is_var), eps, act, slope, _stream())
+    return dx, dres
+
+
+def channel_sum(dy):
+    """sum over N and HW of dy[N][C][HW] (bias gradient)."""
+    dy = _chk(dy, "dy")
+    N, C, HW = _nchw(dy)
+    zero = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 0.0)
+    one = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 1.0)
+    s, _ = bn_bwd_reduce(dy, dy, None, zero, one)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise
+# ------------------------------------------------------------------------------------------------
+def act_fwd(x, act, slope=0.0, out=None):
+    x = _chk(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    lib.rg_act_fwd(_p(x), _p(y), x.numel(), act, slope, _stream())
+    return y
+
+
+def act_bwd(dy, y, act, slope=0.0):
+    dy, y = _chk(dy, "dy"), _chk(y, "y")
+    dx = torch.empty_like(dy)
+    lib.rg_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, slope, _stream())
+    return dx
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    y = out if out is not None else torch.empty_like(a)
+    lib.rg_axpby(_p(a), _p(b), _p(y), a.numel(), alpha, beta, _stream())
+    return y
+
+
+def add(a, b):
+    return axpby(a, b, 1.0, 1.0)
+
+
+def scale(a, alpha):
+    return axpby(a, None, alpha, 0.0)
+
+
+def fill_(t, v):
+    lib.rg_fill(_p(t), t.numel(), float(v), _stream())
+    return t
+
+
+def zeros(shape, device):
+    return fill_(torch.empty(shape, dtype=torch.float32, device=device), 0.0)
+
+
+def sub_square_fwd(a, b):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    y = torch.empty_like(a)
+    lib.rg_sub_square_fwd(_p(a), _p(b), _p(y), a.numel(), _stream())
+    return y
+
+
+def sub_square_bwd(a, b, dy, need_a=True, need_b=True):
+    a, b, dy = _chk(a, "a"), _chk(b, "b"), _chk(dy, "dy")
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(a) if need_b else None
+    lib.rg_sub_square_bwd(_p(a), _p(b), _p(dy), _p(da), _p(db), a.numel(), _stream())
+    return da, db
+
+
+def dropout(x, p, seed):
+    x = _chk(x, "x")
+    y = torch.empty_like(x)
+    lib.rg_dropout(_p(x), _p(y), x.numel(), p, seed, _stream())
+    return y
+
+
+def l2norm_rows_fwd(x, eps=1e-12):
+    x = _chk(x, "x")
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib.rg_l2norm_rows_fwd(_p(x), _p(y), _p(norm), rows, D, eps, _stream())
+    return y, norm
+
+
+def l2norm_rows_bwd(y, dy, norm, eps=1e-12):
+    y, dy = _chk(y, "y"), _chk(dy, "dy")
+    rows, D = y.shape
+    dx = torch.empty_like(y)
+    lib.rg_l2norm_rows_bwd(_p(y), _p(dy), _p(norm), _p(dx), rows, D, eps, _stream())
+    return dx
+
+
+def copy_channels(src, dst, c_count, src_c0, dst_c0, accumulate=False):
+    src, dstc = _chk(src, "src"), dst
+    if not dst.is_contiguous():
+        raise ValueError("copy_channels: destination must be contiguous")
+    N, Cs, HW = _nchw(src)
+    Nd, Cd, HWd = _nchw(dst)
+    if N != Nd or HW != HWd:
+        raise ValueError("copy_channels: batch / spatial mismatch")
+    lib.rg_copy_channels(_p(src), _p(dstc), N, c_count, HW, Cs, src_c0, Cd, dst_c0, int(accumulate), _stream())
+    return dst
+
+
+def cat_channels(tensors):
+    """torch.cat(tensors, dim=1) for NCHW (or NC) tensors."""
+    N = tensors[0].shape[0]
+    Ct = sum(t.shape[1] for t in tensors)
+    out = torch.empty((N, Ct) + tuple(tensors[0].shape[2:]), dtype=torch.float32, device=tensors[0].device)
+    c0 = 0
+    for t in tensors:
+        copy_channels(t, out, t.shape[1], 0, c0)
+        c0 += t.shape[1]
+    return out
+
+
+def slice_channels(src, c0, c1):
+    out = torch.empty((src.shape[0], c1 - c0) + tuple(src.shape[2:]), dtype=torch.float32, device=src.device)
+    return copy_channels(src, out, c1 - c0, c0, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling
+# ------------------------------------------------------------------------------------------------
+def maxpool2d_fwd(x, kernel=3, stride=2, padding=1):
+    x = _chk(x, "x")
+    N, C, H, W = x.shape
+    kh, kw = _pair(kernel)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    P, Q = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    y = torch.empty((N, C, P, Q), dtype=torch.float32, device=x.device)
+    arg = torch.empty((N, C, P, Q), dtype=torch.uint8, device=x.device)
+    lib.rg_maxpool2d_fwd(_p(x), _p(y), _p(arg), N, C, H, W, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+    return y, arg
+
+
+def maxpool2d_bwd(dy, arg, x_shape, kernel=3, stride=2, padding=1):
+    dy = _chk(dy, "dy")
+    N, C, H, W = x_shape
+    kh, kw = _pair(kernel)
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    P, Q = dy.shape[2], dy.shape[3]
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    lib.rg_maxpool2d_bwd(_p(dy), _p(arg), _p(dx), N, C, H, W, kh, kw, sh, sw, ph, pw, P, Q, _stream())
+    return dx
+
+
+def global_avgpool_fwd(x):
+    x = _chk(x, "x")
+    N, C, HW = _nchw(x)
+    y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    lib.rg_global_avgpool_fwd(_p(x), _p(y), N, C, HW, _stream())
+    return y
+
+
+def global_avgpool_bwd(dy, x_shape):
+    dy = _chk(dy, "dy")
+    N, C = x_shape[0], x_shape[1]
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=dy.device)
+    lib.rg_global_avgpool_bwd(_p(dy), _p(dx), N, C, dx.numel() // (N * C), _stream())
+    return dx
+
+
+def gem_pool_fwd(x, p, eps=1e-6):
+    x, p = _chk(x, "x"), _chk(p, "p")
+    N, C, HW = _nchw(x)
+    y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    lib.rg_gem_pool_fwd(_p(x), _p(p), _p(y), N, C, HW, eps, _stream())
+    return y
+
+
+def gem_pool_bwd(x, p, y, dy, eps=1e-6, need_dp=True):
+    x, p, y, dy = _chk(x, "x"), _chk(p, "p"), _chk(y, "y"), _chk(dy, "dy")
+    N, C, HW = _nchw(x)
+    dx = torch.empty_like(x)
+    dp = torch.empty(1, dtype=torch.float32, device=x.device) if need_dp else None
+    ws = workspace(N * C * 4, x.device)
+    lib.rg_gem_pool_bwd(_p(x), _p(p), _p(y), _p(dy), _p(dx), _p(dp), N, C, HW, eps, _p(ws), ws.numel(), _stream())
+    return dx, dp
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+def _loss_ws(device):
+    return workspace(lib.rg_loss_workspace(), device)
+
+
+def sigmoid_bce_fwd(x, target):
+    x = _chk(x, "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = _loss_ws(x.device)
+    lib.rg_sigmoid_bce_fwd(_p(x), _p(out), x.numel(), float(target), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def sigmoid_bce_bwd(x, grad_out, target, grad_scale=1.0):
+    x = _chk(x, "x")
+    dx = torch.empty_like(x)
+    lib.rg_sigmoid_bce_bwd(_p(x), _p(grad_out), _p(dx), x.numel(), float(target), grad_scale, _stream())
+    return dx
+
+
+def mse_const_fwd(x, target):
+    x = _chk(x, "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = _loss_ws(x.device)
+    lib.rg_mse_const_fwd(_p(x), _p(out), x.numel(), float(target), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def mse_const_bwd(x, grad_out, target, grad_scale=1.0):
+    x = _chk(x, "x")
+    dx = torch.empty_like(x)
+    lib.rg_mse_const_bwd(_p(x), _p(grad_out), _p(dx), x.numel(), float(target), grad_scale, _stream())
+    return dx
+
+
+def l1_fwd(a, b, row_labels=None):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    row_labels = _chk(row_labels, "row_labels", torch.int64)
+    rows = a.shape[0]
+    inner = a.numel() // rows
+    out2 = torch.empty(2, dtype=torch.float32, device=a.device)
+    ws = _loss_ws(a.device)
+    lib.rg_l1_fwd(_p(a), _p(b), _p(row_labels), _p(out2), rows, inner, _p(ws), ws.numel(), _stream())
+    return out2
+
+
+def l1_bwd(a, b, row_labels, grad_out, out2, need_a=True, need_b=True, grad_scale=1.0):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    rows = a.shape[0]
+    inner = a.numel() // rows
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(a) if need_b else None
+    lib.rg_l1_bwd(_p(a), _p(b), _p(row_labels), _p(grad_out), _p(out2), _p(da), _p(db), rows, inner, grad_scale,
+                  _stream())
+    return da, db
+
+
+def softmax_ce_fwd(logits, labels, scale=1.0):
+    logits = _chk(logits, "logits")
+    labels = _chk(labels, "labels", torch.int64)
+    B, K = logits.shape
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+    lib.rg_softmax_ce_fwd(_p(logits), _p(labels), _p(loss), _p(lse), B, K, scale, _stream())
+    return loss, lse
+
+
+def softmax_ce_bwd(logits, labels, lse, grad_rows, scale=1.0, grad_scale=1.0):
+    logits = _chk(logits, "logits")
+    grad_rows = _chk(grad_rows, "grad_rows")
+    B, K = logits.shape
+    dz = torch.empty_like(logits)
+    lib.rg_softmax_ce_bwd(_p(logits), _p(labels), _p(lse), _p(grad_rows), _p(dz), B, K, scale, grad_scale, _stream())
+    return dz
+
+
+def weighted_sum_fwd(x, w=None, scale=1.0):
+    x, w = _chk(x, "x"), _chk(w, "w")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    lib.rg_weighted_sum_fwd(_p(x), _p(w), _p(out), x.numel(), scale, _stream())
+    return out
+
+
+def weighted_sum_bwd(grad_out, w, n, scale, device):
+    dx = torch.empty(n, dtype=torch.float32, device=device)
+    lib.rg_weighted_sum_bwd(_p(grad_out), _p(w), _p(dx), n, scale, _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# cluster memory
+# ------------------------------------------------------------------------------------------------
+def cm_update(inputs, targets, features, momentum, hard=False, normalize_eps=False):
+    inputs = _chk(inputs, "inputs")
+    targets = _chk(targets, "targets", torch.int64)
+    if not (features.is_cuda and features.is_contiguous() and features.dtype == torch.float32):
+        raise RuntimeError("cm_update: the memory bank must be a contiguous fp32 GPU tensor (updated in place)")
+    B, D = inputs.shape
+    K = features.shape[0]
+    if hard:
+        lib.rg_cm_update_hard(_p(inputs), _p(targets), _p(features), B, D, K, float(momentum), _stream())
+    else:
+        lib.rg_cm_update(_p(inputs), _p(targets), _p(features), B, D, K, float(momentum), int(normalize_eps), _stream())
+    return features
+
+
+# ------------------------------------------------------------------------------------------------
+# optimizers
+# ------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    lib.rg_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                     _stream())
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
+    lib.rg_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay, int(first_step), grad_scale, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# profiler
+# ------------------------------------------------------------------------------------------------
+def profile_enable(on=True):
+    lib.rg_profile_enable(int(on))
+
+
+def profile_reset():
+    lib.rg_profile_reset()
+
+
+def profile_collect():
+    import ctypes
+    from .lib import FAMILIES
+    n = lib.rg_family_count()
+    ms = (ctypes.c_double * n)()
+    fl = (ctypes.c_double * n)()
+    by = (ctypes.c_double * n)()
+    calls = (ctypes.c_longlong * n)()
+    lib.rg_profile_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(by), ctypes.addressof(calls))
+    return {FAMILIES[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "calls": calls[i]} for i in range(n)}

@@ -1,0 +1,107 @@
+"""Tape runtime: every network is ONE torch.autograd node whose forward/backward run a hand-written
+program of HIP kernel launches (no per-op autograd dispatch, no tracing compiler).
+
+An RGModule is a torch.nn.Module (parameters / buffers / state_dict / train()/eval() behave as in the
+reference) that also implements
+    tf(tape, *inputs)            -> outputs      forward program; pushes what backward needs
+    tb(tape, *grad_outputs, need_dx=True) -> input grads; pops in reverse order, records parameter
+                                                 gradients with tape.add_grad(param, g)
+Calling the module (forward) wraps the whole program in `_NetFn`, so `loss.backward()`,
+`optimizer.step()` and `.grad` work exactly like with the reference's modules.
+"""
+from __future__ import absolute_import
+
+import contextlib
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Tape(object):
+    __slots__ = ("stack", "grads", "param_grad", "record")
+
+    def __init__(self, param_grad=True, record=True):
+        self.stack = []
+        self.grads = {}
+        self.param_grad = param_grad
+        self.record = record
+
+    def push(self, item):
+        if self.record:
+            self.stack.append(item)
+
+    def pop(self):
+        return self.stack.pop()
+
+    def wants(self, p):
+        return self.param_grad and p is not None and p.requires_grad
+
+    def add_grad(self, p, g):
+        k = id(p)
+        if g.shape != p.shape:
+            g = g.view(p.shape)
+        prev = self.grads.get(k)
+        self.grads[k] = g if prev is None else ops.add(prev, g)
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, n_in, *tensors):
+        xs, params = tensors[:n_in], tensors[n_in:]
+        tape = Tape(param_grad=len(params) > 0)
+        ctx.set_materialize_grads(False)
+        outs = net.tf(tape, *[x.detach() if isinstance(x, torch.Tensor) else x for x in xs])
+        ctx.tape, ctx.net, ctx.params, ctx.n_in = tape, net, params, n_in
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dys):
+        tape, n_in = ctx.tape, ctx.n_in
+        if tape is None:
+            raise RuntimeError("rg_hip: backward through a network a second time (the tape is freed after backward)")
+        need = ctx.needs_input_grad[2:2 + n_in]
+        dxs = ctx.net.tb(tape, *dys, need_dx=any(need))
+        if not isinstance(dxs, (tuple, list)):
+            dxs = (dxs,)
+        dxs = tuple(dxs) + (None,) * (n_in - len(dxs))
+        grads = tuple(tape.grads.get(id(p)) for p in ctx.params)
+        ctx.tape = None
+        return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + grads
+
+
+def run(net, *xs):
+    """Execute `net` as one autograd node (or plainly when no gradient is required)."""
+    grad_on = torch.is_grad_enabled()
+    frozen = getattr(net, "_rg_frozen", False)
+    params = [] if (frozen or not grad_on) else [p for p in net.parameters() if p.requires_grad]
+    need_graph = grad_on and (len(params) > 0 or any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs))
+    if not need_graph:
+        return net.tf(Tape(param_grad=False, record=False), *xs)
+    return _NetFn.apply(net, len(xs), *xs, *params)
+
+
+class RGModule(nn.Module):
+    def tf(self, tape, *xs):
+        raise NotImplementedError
+
+    def tb(self, tape, *dys, **kw):
+        raise NotImplementedError
+
+    def forward(self, *xs):
+        return run(self, *xs)
+
+
+@contextlib.contextmanager
+def no_param_grad(*nets):
+    """Within the block the given networks propagate input gradients only (their parameters are
+    treated as constants) — e.g. the discriminators inside the generator update."""
+    old = [getattr(n, "_rg_frozen", False) for n in nets]
+    for n in nets:
+        n._rg_frozen = True
+    try:
+        yield
+    finally:
+        for n, o in zip(nets, old):
+            n._rg_frozen = o

@@ -1,0 +1,333 @@
+"""Op-level parity of every HIP kernel family against plain PyTorch CPU ops (fp64 reference).
+
+These run on the MI355X only (-m gpu) and call through the C ABI (rg_hip.ops -> libreidgan_hip.so).
+Tolerance: fp32 accumulation over K terms; we require max|err| <= 2e-5 * (sum|a||b| scale) which is
+far inside the 1e-3 relative budget of the north star.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from rg_hip import ops
+    return ops
+
+
+def _close(got, ref, tol=2e-5, name=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e)" % (name, err, scale, err / scale)
+
+
+# (N, C, H, W, K, KH, KW, stride, pad)   — every geometry of the reference networks at reduced batch/width
+CONV_CASES = [
+    (2, 3, 64, 32, 64, 7, 7, 2, 3),      # ResNet stem (Kg = 147, scalar weight path)
+    (2, 64, 16, 8, 64, 1, 1, 1, 0),      # bottleneck 1x1
+    (2, 64, 16, 8, 256, 1, 1, 1, 0),
+    (3, 32, 16, 8, 32, 3, 3, 1, 1),      # bottleneck 3x3
+    (2, 128, 16, 8, 128, 3, 3, 2, 1),    # stride-2 3x3
+    (2, 256, 16, 8, 512, 1, 1, 2, 0),    # downsample 1x1/2
+    (2, 18, 64, 32, 64, 4, 4, 2, 1),     # G en_conv1
+    (2, 64, 32, 16, 128, 4, 4, 2, 1),    # G/D 4x4/2
+    (2, 21, 64, 32, 64, 4, 4, 2, 1),     # D_pd first conv
+    (2, 64, 9, 7, 96, 4, 4, 1, 1),       # D_pd stride-1 4x4 (odd sizes)
+    (2, 96, 8, 6, 1, 4, 4, 1, 1),        # D_pd 1-channel head (M = 1)
+    (4, 512, 8, 4, 128, (8, 4), None, 1, 0),   # G en_avg (8,4) valid
+    (1, 5, 7, 5, 3, 3, 3, 1, 1),         # tiny, ragged everything
+    (5, 2048, 1, 1, 2, 1, 1, 1, 0),      # Linear 2048 -> 2 as 1x1
+    (64, 512, 1, 1, 640, 1, 1, 1, 0),    # CM-style GEMM
+    (3, 16, 17, 9, 24, 3, 3, 2, 1),      # odd spatial, stride 2
+]
+
+
+def _geom(case):
+    N, C, H, W, K, KH, KW, s, p = case
+    if isinstance(KH, tuple):
+        KH, KW = KH
+    return N, C, H, W, K, KH, KW, s, p
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    ops = _ops()
+    N, C, H, W, K, KH, KW, s, p = _geom(case)
+    g = torch.Generator().manual_seed(1234 + N * 7 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, KH, KW, generator=g) / math.sqrt(C * KH * KW)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv2d(xd, wd, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+
+    y = ops.conv2d_fwd(x.to(dev), w.to(dev), s, p)
+    _close(y, y_ref, name="fwd")
+    dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p)
+    _close(dx, xd.grad, name="dgrad")
+    dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), (K, C, KH, KW), s, p)
+    _close(dw, wd.grad, tol=5e-5, name="wgrad")
+
+
+def test_conv_fused_epilogue(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 40, 12, 10, generator=g)
+    w = torch.randn(72, 40, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(72, generator=g) + 0.5, torch.randn(72, generator=g)
+    res = torch.randn(3, 72, 12, 10, generator=g)
+    ref = F.conv2d(x.double(), w.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double()
+    for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_LEAKY, lambda t: F.leaky_relu(t, 0.2)), (ops.ACT_TANH, torch.tanh)):
+        y = ops.conv2d_fwd(x.to(dev), w.to(dev), 1, 1, scale=sc.to(dev), shift=sh.to(dev), residual=res.to(dev), act=act,
+                           slope=0.2)
+        _close(y, fn(ref), name="epilogue act=%d" % act)
+
+
+@pytest.mark.parametrize("case", [
+    (2, 2432, 1, 1, 64, (8, 4), 1, 0, 0),    # G de_avg ConvTranspose (8,4) on a 1x1 map
+    (2, 64, 8, 4, 64, (4, 4), 2, 1, 0),      # G decoder 4x4/2
+    (3, 32, 16, 8, 3, (4, 4), 2, 1, 0),      # final 64->3 (tiny M)
+    (2, 24, 8, 4, 16, (3, 3), 2, 1, 1),      # dual_gan 3x3/2 with output_padding 1
+])
+def test_conv_transpose(dev, case):
+    ops = _ops()
+    N, Cin, H, W, Cout, (KH, KW), s, p, op = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, KH, KW, generator=g) / math.sqrt(Cin)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv_transpose2d(xd, wd, stride=s, padding=p, output_padding=op)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    Ho, Wo = y_ref.shape[2:]
+    y = ops.conv2d_dgrad(x.to(dev), w.to(dev), (Ho, Wo), s, p)          # convT forward == dgrad
+    _close(y, y_ref, name="convT fwd")
+    dx = ops.conv2d_fwd(dy.to(dev), w.to(dev), s, p)                    # convT dgrad == conv fwd
+    _close(dx, xd.grad, name="convT dgrad")
+    dw = ops.conv2d_wgrad(dy.to(dev), x.to(dev), (Cin, Cout, KH, KW), s, p)   # roles of x / dy swapped
+    _close(dw, wd.grad, tol=5e-5, name="convT wgrad")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 16, 8), (3, 10, 7, 5), (16, 2048), (2, 512, 31, 15)])
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm(dev, shape, train):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    res = torch.randn(shape, generator=g)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    resd = res.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y_ref = F.relu(F.batch_norm(xd, rm_ref, rv_ref, gd, bd, training=train, momentum=0.1, eps=1e-5) + resd)
+    dy = torch.randn(shape, generator=g)
+    y_ref.backward(dy.double())
+
+    xg, rmg, rvg = x.to(dev), rm.to(dev), rv.to(dev)
+    if train:
+        mean, stat = ops.bn_stats(xg, rmg, rvg, 1e-5, 0.1)
+        is_var = False
+        _close(rmg, rm_ref, name="running_mean")
+        _close(rvg, rv_ref, name="running_var")
+    else:
+        mean, stat, is_var = rmg, rvg, True
+    y = ops.bn_apply_fwd(xg, mean, stat, gamma.to(dev), beta.to(dev), res.to(dev), is_var, 1e-5, ops.ACT_RELU)
+    _close(y, y_ref, name="bn fwd")
+    s1, s2 = ops.bn_bwd_reduce(xg, dy.to(dev), y, mean, stat, is_var, 1e-5, ops.ACT_RELU)
+    _close(s1, bd.grad, tol=5e-5, name="dbeta")
+    _close(s2, gd.grad, tol=5e-5, name="dgamma")
+    dx, dres = ops.bn_bwd_apply(xg, dy.to(dev), y, mean, stat, gamma.to(dev), s1, s2, train, is_var, 1e-5,
+                                ops.ACT_RELU, need_dx=True, need_dres=True)
+    _close(dx, xd.grad, tol=5e-5, name="bn dx")
+    _close(dres, resd.grad, name="bn dres")
+
+
+def test_activations_and_misc(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 7, 5, 3, generator=g)
+    dy = torch.randn(3, 7, 5, 3, generator=g)
+    for act, fn in ((ops.ACT_RELU, F.relu), (ops.ACT_LEAKY, lambda t: F.leaky_relu(t, 0.2)), (ops.ACT_TANH, torch.tanh)):
+        xd = x.double().requires_grad_(True)
+        yr = fn(xd)
+        yr.backward(dy.double())
+        y = ops.act_fwd(x.to(dev), act, 0.2)
+        _close(y, yr, name="act fwd")
+        _close(ops.act_bwd(dy.to(dev), y, act, 0.2), xd.grad, name="act bwd")
+    a, b = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    _close(ops.axpby(a.to(dev), b.to(dev), 0.5, -2.0), 0.5 * a.double() - 2.0 * b.double(), name="axpby")
+    ad, bd_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = (ad - bd_).pow(2)
+    d = torch.randn(1000, generator=g)
+    yr.backward(d.double())
+    _close(ops.sub_square_fwd(a.to(dev), b.to(dev)), yr, name="subsq")
+    da, db = ops.sub_square_bwd(a.to(dev), b.to(dev), d.to(dev))
+    _close(da, ad.grad, name="subsq da")
+    _close(db, bd_.grad, name="subsq db")
+    # l2 normalize rows
+    m = torch.randn(9, 2048, generator=g)
+    md = m.double().requires_grad_(True)
+    yr = F.normalize(md, dim=1)
+    gy = torch.randn(9, 2048, generator=g)
+    yr.backward(gy.double())
+    y, nrm = ops.l2norm_rows_fwd(m.to(dev))
+    _close(y, yr, name="l2norm")
+    _close(ops.l2norm_rows_bwd(y, gy.to(dev), nrm), md.grad, name="l2norm bwd")
+    # channel cat / slice
+    t1, t2 = torch.randn(2, 3, 4, 5, generator=g), torch.randn(2, 18, 4, 5, generator=g)
+    cat = ops.cat_channels([t1.to(dev), t2.to(dev)])
+    _close(cat, torch.cat([t1, t2], 1), tol=0, name="cat")
+    _close(ops.slice_channels(cat, 3, 21), t2, tol=0, name="slice")
+    # dropout: scaling and keep-rate
+    xx = torch.ones(1 << 16)
+    yy = ops.dropout(xx.to(dev), 0.2, 12345).cpu()
+    keep = (yy != 0).float().mean().item()
+    assert abs(keep - 0.8) < 0.01
+    assert torch.allclose(yy[yy != 0], torch.tensor(1.25))
+    assert torch.equal(yy, ops.dropout(xx.to(dev), 0.2, 12345).cpu())
+
+
+def test_pooling(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, 17, 9, generator=g).relu()      # zeros -> ties, like post-ReLU stem output
+    xd = x.double().requires_grad_(True)
+    yr = F.max_pool2d(xd, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    y, arg = ops.maxpool2d_fwd(x.to(dev), 3, 2, 1)
+    _close(y, yr, tol=0, name="maxpool")
+    _close(ops.maxpool2d_bwd(dy.to(dev), arg, x.shape, 3, 2, 1), xd.grad, name="maxpool bwd")
+    # global average
+    x = torch.randn(3, 40, 8, 4, generator=g)
+    xd = x.double().requires_grad_(True)
+    yr = F.avg_pool2d(xd, xd.shape[2:]).flatten(1)
+    dy = torch.randn(3, 40, generator=g)
+    yr.backward(dy.double())
+    _close(ops.global_avgpool_fwd(x.to(dev)), yr, name="gap")
+    _close(ops.global_avgpool_bwd(dy.to(dev), x.shape), xd.grad, name="gap bwd")
+    # GeM
+    x = torch.randn(3, 40, 16, 8, generator=g)
+    p = torch.tensor([3.0])
+    xd, pd_ = x.double().requires_grad_(True), p.double().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xd.clamp(min=1e-6).pow(pd_), 1).pow(1.0 / pd_).flatten(1)
+    yr.backward(dy.double())
+    y = ops.gem_pool_fwd(x.to(dev), p.to(dev))
+    _close(y, yr, tol=1e-4, name="gem")
+    dx, dp = ops.gem_pool_bwd(x.to(dev), p.to(dev), y, dy.to(dev))
+    _close(dx, xd.grad, tol=1e-4, name="gem dx")
+    _close(dp, pd_.grad, tol=1e-3, name="gem dp")
+
+
+def test_losses(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 1, 30, 14, generator=g) * 3
+    for target in (1.0, 0.0, 0.83):
+        xd = x.double().requires_grad_(True)
+        lr = F.binary_cross_entropy(torch.sigmoid(xd), torch.full_like(xd, target))
+        (lr * 0.5).backward()
+        _close(ops.sigmoid_bce_fwd(x.to(dev), target), lr, name="bce")
+        gout = torch.tensor(0.5, device=dev)
+        _close(ops.sigmoid_bce_bwd(x.to(dev), gout, target), xd.grad, name="bce bwd")
+        xd = x.double().requires_grad_(True)
+        lr = F.mse_loss(xd, torch.full_like(xd, target))
+        lr.backward()
+        _close(ops.mse_const_fwd(x.to(dev), target), lr, name="mse")
+        _close(ops.mse_const_bwd(x.to(dev), None, target), xd.grad, name="mse bwd")
+    a, b = torch.randn(6, 3, 16, 8, generator=g), torch.randn(6, 3, 16, 8, generator=g)
+    ad, bd_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    lr = F.l1_loss(ad, bd_)
+    lr.backward()
+    out2 = ops.l1_fwd(a.to(dev), b.to(dev))
+    _close(out2[0], lr, name="l1")
+    da, db = ops.l1_bwd(a.to(dev), b.to(dev), None, None, out2)
+    _close(da, ad.grad, name="l1 da")
+    _close(db, bd_.grad, name="l1 db")
+    labels = torch.tensor([1, 0, 0, 1, 0, 1])
+    ad, bd_ = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    mask = labels.view(-1, 1, 1, 1).expand_as(ad) == 1
+    lr = F.l1_loss(ad[mask], bd_[mask])
+    (lr * 10).backward()
+    out2 = ops.l1_fwd(a.to(dev), b.to(dev), labels.to(dev))
+    _close(out2[0], lr, name="masked l1")
+    da, db = ops.l1_bwd(a.to(dev), b.to(dev), labels.to(dev), torch.tensor(10.0, device=dev), out2)
+    _close(da, ad.grad, name="masked l1 da")
+    # nothing selected -> NaN like torch
+    assert torch.isnan(ops.l1_fwd(a.to(dev), b.to(dev), torch.zeros(6, dtype=torch.long, device=dev))[0]).item()
+    # softmax CE with temperature
+    z = torch.randn(8, 2048, generator=g)
+    y = torch.randint(0, 2048, (8,), generator=g)
+    zd = z.double().requires_grad_(True)
+    lrows = F.cross_entropy(zd / 0.05, y, reduction="none")
+    wts = torch.rand(8, generator=g)
+    (lrows * wts.double()).sum().backward()
+    loss, lse = ops.softmax_ce_fwd(z.to(dev), y.to(dev), 1 / 0.05)
+    _close(loss, lrows, name="ce")
+    _close(ops.softmax_ce_bwd(z.to(dev), y.to(dev), lse, wts.to(dev), 1 / 0.05), zd.grad, name="ce bwd")
+    _close(ops.weighted_sum_fwd(loss, wts.to(dev), 0.125), (lrows * wts.double()).sum() * 0.125, name="wsum")
+
+
+def test_cm_update(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    K, D, B = 50, 2048, 24
+    feats = F.normalize(torch.randn(K, D, generator=g), dim=1)
+    x = F.normalize(torch.randn(B, D, generator=g), dim=1)
+    y = torch.tensor([3, 3, 7, 3, 9, 7, 7, 3] * 3)
+    ref = feats.double().clone()
+    m = 0.2
+    for xi, yi in zip(x.double(), y):
+        ref[yi] = m * ref[yi] + (1 - m) * xi
+        ref[yi] /= ref[yi].norm()
+    fg = feats.to(dev).clone()
+    ops.cm_update(x.to(dev), y.to(dev), fg, m)
+    _close(fg, ref, name="cm update")
+    # hard variant: per label, the sample with the smallest similarity
+    ref = feats.double().clone()
+    for lab in y.unique().tolist():
+        idx = (y == lab).nonzero().flatten()
+        sims = x.double()[idx] @ ref[lab]
+        j = idx[sims.argmin()]
+        ref[lab] = ref[lab] * m + (1 - m) * x.double()[j]
+        ref[lab] /= ref[lab].norm()
+    fg = feats.to(dev).clone()
+    ops.cm_update(x.to(dev), y.to(dev), fg, m, hard=True)
+    _close(fg, ref, name="cm hard update")
+
+
+def test_optimizers(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    n = 1003
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    pr = p0.double().clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-3, betas=(0.5, 0.999), weight_decay=5e-4)
+    pg = torch.zeros(1008, device=dev)[:n]
+    pg.copy_(p0)
+    mg, vg = torch.zeros(1008, device=dev)[:n], torch.zeros(1008, device=dev)[:n]
+    for t, gr in enumerate(grads, 1):
+        pr.grad = gr.double()
+        opt.step()
+        gg = torch.zeros(1008, device=dev)[:n]
+        gg.copy_(gr)
+        ops.adam_step(pg, gg, mg, vg, 2e-3, 0.5, 0.999, 1e-8, 5e-4, t)
+    _close(pg, pr, name="adam")
+    pr = p0.double().clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pg = p0.to(dev).clone()
+    buf = torch.zeros(n, device=dev)
+    for t, gr in enumerate(grads):
+        pr.grad = gr.double()
+        opt.step()
+        ops.sgd_step(pg, gr.to(dev), buf, 0.01, 0.9, 1e-4, t == 0)
+    _close(pg, pr, name="sgd")
