@@ -1,0 +1,321 @@
+"""FDGANModel — restates the step driver FD-GAN-master/fdgan/model.py:21-264 on the HIP runtime.
+
+Same constructor (`FDGANModel(opt)`), public attributes (net_E / net_G / net_Di / net_Dp, each exposing
+`.module`; optimizer_G / optimizer_Di / optimizer_Dp; schedulers) and methods (set_input, forward,
+backward_Dp, backward_Di, backward_G, optimize_parameters, get_current_errors, get_current_visuals,
+save, update_learning_rate, reset_model_status).  The arithmetic of every method is the reference's;
+what differs is how it is scheduled on the MI355X:
+
+  * backward_Di evaluates D_id(origin, target) and D_id(origin, fake) as ONE trunk pass over
+    [origin | target | fake] (eval-mode BatchNorm makes samples independent; the shared origin branch
+    is computed once and receives both gradients)                                     (reference :176-177)
+  * backward_Dp runs D_pd on [real_pose | fake_pose] separately (train-mode BN: batches must stay
+    separate to keep the reference's statistics)                                          (:160-163)
+  * backward_G treats D_id / D_pd as constants: their weight gradients, which the reference computes
+    and then throws away at the next zero_grad(), are not computed                         (:196-204)
+  * one process drives one GPU; `.module` wrappers are kept for API compatibility, gradients are
+    all-reduced over RCCL by rg_hip.parallel when torch.distributed is initialised.
+
+Defects of the reference that are NOT reproduced: `.data[0]` on 0-dim tensors (-> .item()),
+the D_id classifier slice that loses a dimension (:56-57, kept as [1,2048]).
+"""
+from __future__ import absolute_import
+
+import os
+import random
+from collections import OrderedDict
+
+import torch
+
+from fdgan.losses import GANLoss
+from fdgan.networks import (CustomPoseGenerator, NLayerDiscriminator, get_norm_layer, get_scheduler, init_weights,
+                            print_network, remove_module_key, set_bn_fix)
+from reid.models import create
+from reid.models.embedding import EltwiseSubEmbed
+from reid.models.multi_branch import SiameseNet
+from rg_hip import functional as RF
+from rg_hip import ops
+from rg_hip import optim as roptim
+from rg_hip.parallel import DataParallel, GradReducer
+from rg_hip.tape import no_param_grad
+
+
+def _weighted(terms):
+    """sum_i w_i * loss_i of 0-dim device losses in one kernel (keeps the autograd graph)."""
+    vals = torch.stack([t for t, _ in terms])
+    w = torch.tensor([float(w) for _, w in terms], dtype=torch.float32).to(vals.device, non_blocking=True)
+    return RF._WeightedSum.apply(vals, w, 1.0)
+
+
+class FDGANModel(object):
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.save_dir = os.path.join(opt.checkpoints, opt.name)
+        self.norm_layer = get_norm_layer(norm_type=opt.norm)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+        self._init_models()
+        self._init_losses()
+        self._init_optimizers()
+
+        if not getattr(opt, "quiet", False):
+            print('---------- Networks initialized -------------')
+            print_network(self.net_E)
+            print_network(self.net_G)
+            print_network(self.net_Di)
+            print_network(self.net_Dp)
+            print('-----------------------------------------------')
+
+    def _init_models(self):
+        opt = self.opt
+        pretrained = bool(getattr(opt, "imagenet_pretrained", False))
+        self.net_G = CustomPoseGenerator(opt.pose_feature_size, 2048, opt.noise_feature_size,
+                                         dropout=opt.drop, norm_layer=self.norm_layer, fuse_mode=opt.fuse_mode,
+                                         connect_layers=opt.connect_layers)
+        e_base_model = create(opt.arch, cut_at_pooling=True, pretrained=pretrained)
+        e_embed_model = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=2)
+        self.net_E = SiameseNet(e_base_model, e_embed_model)
+
+        di_base_model = create(opt.arch, cut_at_pooling=True, pretrained=pretrained)
+        di_embed_model = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=1)
+        self.net_Di = SiameseNet(di_base_model, di_embed_model)
+        self.net_Dp = NLayerDiscriminator(3 + 18, norm_layer=self.norm_layer)
+
+        random_init = bool(getattr(opt, "random_init", False))      # synthetic benchmarks / tests: no checkpoints
+        if opt.stage == 1:
+            init_weights(self.net_G)
+            init_weights(self.net_Dp)
+            if not random_init:
+                state_dict = remove_module_key(torch.load(opt.netE_pretrain, map_location="cpu"))
+                self.net_E.load_state_dict(state_dict)
+                state_dict = dict(state_dict)
+                state_dict['embed_model.classifier.weight'] = state_dict['embed_model.classifier.weight'][1:2]
+                state_dict['embed_model.classifier.bias'] = state_dict['embed_model.classifier.bias'][1:2]
+                self.net_Di.load_state_dict(state_dict)
+        elif opt.stage == 2:
+            if random_init:
+                init_weights(self.net_G)
+                init_weights(self.net_Dp)
+            else:
+                self._load_state_dict(self.net_E, opt.netE_pretrain)
+                self._load_state_dict(self.net_G, opt.netG_pretrain)
+                self._load_state_dict(self.net_Di, opt.netDi_pretrain)
+                self._load_state_dict(self.net_Dp, opt.netDp_pretrain)
+        else:
+            assert ('unknown training stage')
+
+        self.net_E = DataParallel(self.net_E).to(self.device)
+        self.net_G = DataParallel(self.net_G).to(self.device)
+        self.net_Di = DataParallel(self.net_Di).to(self.device)
+        self.net_Dp = DataParallel(self.net_Dp).to(self.device)
+
+    def reset_model_status(self):
+        if self.opt.stage == 1:
+            self.net_G.train()
+            self.net_Dp.train()
+            self.net_E.eval()
+            self.net_Di.train()
+            self.net_Di.apply(set_bn_fix)
+        elif self.opt.stage == 2:
+            self.net_E.train()
+            self.net_G.train()
+            self.net_Di.train()
+            self.net_Dp.train()
+            self.net_E.apply(set_bn_fix)
+            self.net_Di.apply(set_bn_fix)
+
+    def _load_state_dict(self, net, path):
+        state_dict = remove_module_key(torch.load(path, map_location="cpu"))
+        net.load_state_dict(state_dict)
+
+    def _init_losses(self):
+        if self.opt.smooth_label:
+            self.criterionGAN_D = GANLoss(smooth=True)
+            self.rand_list = [True] * 1 + [False] * 10000
+        else:
+            self.criterionGAN_D = GANLoss(smooth=False)
+            self.rand_list = [False]
+        self.criterionGAN_G = GANLoss(smooth=False)
+
+    def _init_optimizers(self):
+        opt = self.opt
+        if opt.stage == 1:
+            self.optimizer_G = roptim.Adam(self.net_G.parameters(), lr=opt.lr * 0.1, betas=(0.5, 0.999))
+            self.optimizer_Di = roptim.SGD(self.net_Di.parameters(), lr=opt.lr * 0.01, momentum=0.9, weight_decay=1e-4)
+            self.optimizer_Dp = roptim.SGD(self.net_Dp.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
+        elif opt.stage == 2:
+            # `lr_mult` is carried in the groups but never applied, exactly as in the reference (:109-113)
+            param_groups = [{'params': self.net_E.module.base_model.parameters(), 'lr_mult': 0.1},
+                            {'params': self.net_E.module.embed_model.parameters(), 'lr_mult': 1.0},
+                            {'params': self.net_G.parameters(), 'lr_mult': 0.1}]
+            self.optimizer_G = roptim.Adam(param_groups, lr=opt.lr * 0.1, betas=(0.5, 0.999))
+            self.optimizer_Di = roptim.SGD(self.net_Di.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
+            self.optimizer_Dp = roptim.SGD(self.net_Dp.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
+
+        self.schedulers = []
+        self.optimizers = []
+        self.optimizers.append(self.optimizer_G)
+        self.optimizers.append(self.optimizer_Di)
+        self.optimizers.append(self.optimizer_Dp)
+        for optimizer in self.optimizers:
+            self.schedulers.append(get_scheduler(optimizer, opt))
+        # data-parallel gradient reduction (no-op unless torch.distributed is initialised)
+        self.reducers = [GradReducer(o) for o in self.optimizers]
+
+    def set_input(self, input):
+        input1, input2 = input
+        labels = (input1['pid'] == input2['pid']).long()
+        noise = input1.get('noise') if isinstance(input1, dict) else None     # tests feed z explicitly
+        if noise is None:
+            noise = torch.randn(labels.size(0), self.opt.noise_feature_size)
+
+        # keep the same pose map for persons with the same identity
+        mask = labels.view(-1, 1, 1, 1).expand_as(input1['posemap'])
+        posemap2 = input1['posemap'] * mask.float() + input2['posemap'] * (1 - mask.float())
+        mask = labels.view(-1, 1, 1, 1).expand_as(input1['target'])
+        target2 = input1['target'] * mask.float() + input2['target'] * (1 - mask.float())
+
+        origin = torch.cat([input1['origin'], input2['origin']])
+        target = torch.cat([input1['target'], target2])
+        posemap = torch.cat([input1['posemap'], posemap2])
+        noise = torch.cat((noise, noise))
+
+        dev = self.device
+        self.origin = origin.to(dev, non_blocking=True).contiguous()
+        self.target = target.to(dev, non_blocking=True).contiguous()
+        self.posemap = posemap.to(dev, non_blocking=True).contiguous()
+        self.labels = labels.to(dev, non_blocking=True).contiguous()
+        self.noise = noise.to(dev, non_blocking=True).contiguous()
+
+    def forward(self):
+        A = self.origin
+        B_map = self.posemap
+        z = self.noise
+        bs = A.size(0)
+
+        A_id1, A_id2, self.id_score = self.net_E(A[:bs // 2], A[bs // 2:])
+        A_id = torch.cat((A_id1, A_id2))
+        self.fake = self.net_G(B_map, A_id.view(A_id.size(0), A_id.size(1), 1, 1), z.view(z.size(0), z.size(1), 1, 1))
+
+    def backward_Dp(self):
+        real_pose = ops.cat_channels([self.posemap, self.target])
+        fake_pose = ops.cat_channels([self.posemap, self.fake.detach()])
+        pred_real = self.net_Dp(real_pose)
+        pred_fake = self.net_Dp(fake_pose)
+
+        if random.choice(self.rand_list):
+            loss_D_real = self.criterionGAN_D(pred_fake, True)
+            loss_D_fake = self.criterionGAN_D(pred_real, False)
+        else:
+            loss_D_real = self.criterionGAN_D(pred_real, True)
+            loss_D_fake = self.criterionGAN_D(pred_fake, False)
+        loss_D = _weighted([(loss_D_real, 0.5), (loss_D_fake, 0.5)])
+        loss_D.backward()
+        self.loss_Dp = loss_D.detach()
+
+    def backward_Di(self):
+        pred_real, pred_fake = self.net_Di.module.forward_shared(self.origin, [self.target, self.fake.detach()])
+        if random.choice(self.rand_list):
+            loss_D_real = self.criterionGAN_D(pred_fake, True)
+            loss_D_fake = self.criterionGAN_D(pred_real, False)
+        else:
+            loss_D_real = self.criterionGAN_D(pred_real, True)
+            loss_D_fake = self.criterionGAN_D(pred_fake, False)
+        loss_D = _weighted([(loss_D_real, 0.5), (loss_D_fake, 0.5)])
+        loss_D.backward()
+        self.loss_Di = loss_D.detach()
+
+    def backward_G(self):
+        loss_v = RF.cross_entropy(self.id_score, self.labels.view(-1))
+        loss_r = RF.l1_loss(self.fake, self.target)
+        half = self.fake.size(0) // 2
+        fake_1 = self.fake[:half]
+        fake_2 = self.fake[half:]
+        loss_sp = RF.l1_loss(fake_1, fake_2, self.labels.view(-1))       # rows with label == 1 (:191-194)
+
+        with no_param_grad(self.net_Di.module, self.net_Dp.module):
+            _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
+            pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
+        loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
+        loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
+
+        loss_G = _weighted([(loss_G_GAN_Di, 1.0), (loss_G_GAN_Dp, 1.0),
+                            (loss_r, self.opt.lambda_recon),
+                            (loss_v, self.opt.lambda_veri),
+                            (loss_sp, self.opt.lambda_sp)])
+        loss_G.backward()
+
+        del self.id_score
+        self.loss_G = loss_G.detach()
+        self.loss_v = loss_v.detach()
+        self.loss_sp = loss_sp.detach()
+        self.loss_r = loss_r.detach()
+        self.loss_G_GAN_Di = loss_G_GAN_Di.detach()
+        self.loss_G_GAN_Dp = loss_G_GAN_Dp.detach()
+        self.fake = self.fake.detach()
+
+    def optimize_parameters(self):
+        self.forward()
+
+        self.optimizer_Di.zero_grad()
+        self.backward_Di()
+        self.reducers[1].reduce()
+        self.optimizer_Di.step()
+
+        self.optimizer_Dp.zero_grad()
+        self.backward_Dp()
+        self.reducers[2].reduce()
+        self.optimizer_Dp.step()
+
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.reducers[0].reduce()
+        self.optimizer_G.step()
+
+    def get_current_errors(self):
+        # one device->host transfer for all seven scalars (the reference synchronises seven times)
+        vals = torch.stack([self.loss_v, self.loss_r, self.loss_sp, self.loss_G_GAN_Di, self.loss_G_GAN_Dp,
+                            self.loss_Di, self.loss_Dp]).tolist()
+        return OrderedDict(zip(['G_v', 'G_r', 'G_sp', 'G_gan_Di', 'G_gan_Dp', 'D_i', 'D_p'], vals))
+
+    def get_current_visuals(self):
+        import fdgan.utils.util as util            # visualisation helpers are outside the hot path
+        input = util.tensor2im(self.origin)
+        target = util.tensor2im(self.target)
+        fake = util.tensor2im(self.fake)
+        map = self.posemap.sum(1)
+        map[map > 1] = 1
+        map = util.tensor2im(torch.unsqueeze(map, 1))
+        return OrderedDict([('input', input), ('posemap', map), ('fake', fake), ('target', target)])
+
+    def save(self, epoch):
+        self.save_network(self.net_E, 'E', epoch)
+        self.save_network(self.net_G, 'G', epoch)
+        self.save_network(self.net_Di, 'Di', epoch)
+        self.save_network(self.net_Dp, 'Dp', epoch)
+
+    def save_network(self, network, network_label, epoch_label):
+        save_filename = '%s_net_%s.pth' % (epoch_label, network_label)
+        os.makedirs(self.save_dir, exist_ok=True)
+        save_path = os.path.join(self.save_dir, save_filename)
+        torch.save({k: v.detach().cpu().clone() for k, v in network.state_dict().items()}, save_path)
+
+    def update_learning_rate(self):
+        for scheduler in self.schedulers:
+            scheduler.step()
+        lr = self.optimizers[0].param_groups[0]['lr']
+        return lr
+
+
+class _CatPose(torch.autograd.Function):
+    """torch.cat((posemap, fake), dim=1) with the gradient sliced back to `fake` (reference :197)."""
+
+    @staticmethod
+    def forward(ctx, posemap, fake):
+        ctx.c0, ctx.c1 = posemap.shape[1], posemap.shape[1] + fake.shape[1]
+        return ops.cat_channels([posemap, fake])
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ops.slice_channels(g, ctx.c0, ctx.c1)

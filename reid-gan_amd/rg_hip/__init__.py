@@ -2,4 +2,4 @@
 tape-based module runtime (tape, nn), fused optimizers (optim) and the data-parallel reducer (parallel)."""
 from __future__ import absolute_import
 
-from .lib import lib, build, LIB_PATH, FAMILIES  # noqa: F401
+from .lib import build, LIB_PATH, FAMILIES  # noqa: F401

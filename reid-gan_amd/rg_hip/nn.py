@@ -52,9 +52,10 @@ class Conv2d(RGModule):
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
         if tape.wants(self.weight):
-            tape.add_grad(self.weight, ops.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding))
+            tape.add_grad(self.weight, ops.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding,
+                                                        out=tape.grad_out(self.weight)))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy))
+            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
         return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual)
@@ -85,6 +86,15 @@ class ConvTranspose2d(RGModule):
 
     def tf(self, tape, x, act=ACT_NONE, slope=0.0):
         hw = self.out_hw(x.shape[2], x.shape[3])
+        if (x.shape[2] == 1 and x.shape[3] == 1 and self.padding == (0, 0) and self.output_padding == (0, 0)
+                and self.bias is None and act == ACT_NONE):
+            # a 1x1 input makes the transposed conv a plain GEMM x[N][K] . w[K][C*KH*KW] (the generator's
+            # 2432 -> 512 (8,4) layer, FD/fdgan/networks.py:105-109): run it with 1x1 geometry so no
+            # MFMA work is spent on taps that fall outside the single input pixel
+            K, C, KH, KW = self.weight.shape
+            y = ops.conv2d_dgrad(x, self.weight.view(K, C * KH * KW, 1, 1), (1, 1), 1, 0).view(x.shape[0], C, KH, KW)
+            tape.push((x, None, act, slope))
+            return y
         y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, act=act, slope=slope)
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
@@ -94,9 +104,10 @@ class ConvTranspose2d(RGModule):
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
         if tape.wants(self.weight):
-            tape.add_grad(self.weight, ops.conv2d_wgrad(dy, x, self.weight.shape, self.stride, self.padding))
+            tape.add_grad(self.weight, ops.conv2d_wgrad(dy, x, self.weight.shape, self.stride, self.padding,
+                                                        out=tape.grad_out(self.weight)))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy))
+            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
         return ops.conv2d_fwd(dy, self.weight, self.stride, self.padding, residual=residual)
@@ -123,9 +134,9 @@ class Linear(RGModule):
     def tb(self, tape, dy, need_dx=True):
         x = tape.pop()
         if tape.wants(self.weight):
-            tape.add_grad(self.weight, ops.linear_wgrad(x, dy))
+            tape.add_grad(self.weight, ops.linear_wgrad(x, dy, out=tape.grad_out(self.weight)))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy))
+            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         return ops.linear_dgrad(dy, self.weight) if need_dx else None
 
 
@@ -172,7 +183,9 @@ class _BatchNorm(RGModule):
         need_affine = tape.wants(self.weight) or tape.wants(self.bias)
         s1 = s2 = None
         if need_affine or (train and need_dx):
-            s1, s2 = ops.bn_bwd_reduce(x, dy, y, mean, stat, is_var, self.eps, act, slope)
+            o1 = tape.grad_out(self.bias) if tape.wants(self.bias) else None
+            o2 = tape.grad_out(self.weight) if tape.wants(self.weight) else None
+            s1, s2 = ops.bn_bwd_reduce(x, dy, y, mean, stat, is_var, self.eps, act, slope, o1, o2)
             if tape.wants(self.weight):
                 tape.add_grad(self.weight, s2)
             if tape.wants(self.bias):
@@ -292,3 +305,44 @@ class Sequential(RGModule):
         for i in range(len(mods) - 1, -1, -1):
             dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
         return dy
+
+
+class InstanceNorm2d(RGModule):
+    """Instance norm == batch norm over a [1][N*C][HW] view with batch statistics (no running stats),
+    so it runs on the same kernels.  affine=False is the FD-GAN setting (FD/fdgan/networks.py:30);
+    affine=True (dual_gan, CC/dual_gan/models/base_function.py:38-48) tiles gamma/beta over N."""
+
+    def __init__(self, num_features, eps=1e-5, affine=False):
+        super(InstanceNorm2d, self).__init__()
+        self.num_features, self.eps, self.affine = num_features, eps, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
+        N, C = x.shape[0], x.shape[1]
+        xv = x.reshape(1, N * C, *x.shape[2:])
+        mean, invstd = ops.bn_stats(xv, None, None, self.eps, 0.0)
+        g = self.weight.detach().repeat(N) if self.affine else None
+        b = self.bias.detach().repeat(N) if self.affine else None
+        rv = residual.reshape(xv.shape) if residual is not None else None
+        y = ops.bn_apply_fwd(xv, mean, invstd, g, b, rv, False, self.eps, act, slope)
+        tape.push((xv, y if act != ACT_NONE else None, mean, invstd, g, act, slope, residual is not None, x.shape))
+        return y.view(x.shape)
+
+    def tb(self, tape, dy, need_dx=True):
+        xv, y, mean, invstd, g, act, slope, has_res, shape = tape.pop()
+        N, C = shape[0], shape[1]
+        dyv = dy.reshape(xv.shape)
+        s1, s2 = ops.bn_bwd_reduce(xv, dyv, y, mean, invstd, False, self.eps, act, slope)
+        if self.affine and tape.wants(self.weight):
+            ones = ops.fill_(torch.empty(1, N, dtype=torch.float32, device=dy.device), 1.0)
+            tape.add_grad(self.weight, ops.linear_fwd(ones, s2.view(N, C).t().contiguous()).view(C))
+            tape.add_grad(self.bias, ops.linear_fwd(ones, s1.view(N, C).t().contiguous()).view(C))
+        dx, dres = ops.bn_bwd_apply(xv, dyv, y, mean, invstd, g, s1, s2, True, False, self.eps, act, slope,
+                                    need_dx=True, need_dres=has_res)
+        dx = dx.view(shape)
+        return (dx, dres.view(shape)) if has_res else dx

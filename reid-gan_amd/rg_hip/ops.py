@@ -138,10 +138,10 @@ def linear_dgrad(dy, w):
     return dx.view(B, w.shape[1])
 
 
-def linear_wgrad(x, dy):
+def linear_wgrad(x, dy, out=None):
     B, Cin = x.shape
     K = dy.shape[1]
-    return conv2d_wgrad(x.view(B, Cin, 1, 1), dy.view(B, K, 1, 1), (K, Cin, 1, 1)).view(K, Cin)
+    return conv2d_wgrad(x.view(B, Cin, 1, 1), dy.view(B, K, 1, 1), (K, Cin, 1, 1), out=out).view(K, Cin)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -175,11 +175,13 @@ def bn_apply_fwd(x, mean, stat, gamma, beta, residual=None, stat_is_var=False, e
     return y
 
 
-def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0):
+def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0,
+                  out_sum_dy=None, out_sum_dy_xhat=None):
     x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
     N, C, HW = _nchw(x)
-    sum_dy = torch.empty(C, dtype=torch.float32, device=x.device)
-    sum_dy_xhat = torch.empty(C, dtype=torch.float32, device=x.device)
+    sum_dy = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    sum_dy_xhat = out_sum_dy_xhat if out_sum_dy_xhat is not None else \
+        torch.empty(C, dtype=torch.float32, device=x.device)
     ws = workspace(lib.rg_bn_workspace(N, C, HW), x.device)
     lib.rg_bn_bwd_reduce(_p(x), _p(dy), _p(y_act), _p(mean), _p(stat), _p(sum_dy), _p(sum_dy_xhat), N, C, HW,
                          int(stat_is_var), eps, act, slope, _p(ws), ws.numel(), _stream())
@@ -197,13 +199,13 @@ def bn_bwd_apply(x, dy, y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, train, st
     return dx, dres
 
 
-def channel_sum(dy):
+def channel_sum(dy, out=None):
     """sum over N and HW of dy[N][C][HW] (bias gradient)."""
     dy = _chk(dy, "dy")
     N, C, HW = _nchw(dy)
     zero = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 0.0)
     one = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 1.0)
-    s, _ = bn_bwd_reduce(dy, dy, None, zero, one)
+    s, _ = bn_bwd_reduce(dy, dy, None, zero, one, out_sum_dy=out)
     return s
 
 

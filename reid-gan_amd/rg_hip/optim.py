@@ -1,0 +1,167 @@
+"""Fused Adam / SGD over flat parameter arenas.
+
+`Adam` / `SGD` take the same arguments as torch.optim.Adam / torch.optim.SGD (the reference builds those:
+FD/fdgan/model.py:100-125, CC/examples/cluster_contrast_gan_train_usl_infomap.py:281-284) and are
+torch.optim.Optimizer subclasses, so schedulers, param_groups, zero_grad() and state_dict() behave the same.
+
+At construction every parameter group is moved into ONE contiguous fp32 arena (p.data becomes a view)
+with a matching gradient arena; the tape runtime writes weight gradients straight into those views
+(`p._rg_grad`), so a step is one kernel launch per run of consecutive parameters that received a
+gradient (normally one per group) instead of ~10 element-wise launches per tensor, and the
+data-parallel reducer can all-reduce the same flat buffer without bucket copies.
+"""
+from __future__ import absolute_import
+
+import torch
+from torch.optim import Optimizer
+
+from . import ops
+
+_ALIGN = 64          # elements; keeps every view 256-byte aligned (float4 kernels, RCCL)
+
+
+class Arena(object):
+    """Flat storage for a list of parameters (values + gradients)."""
+
+    def __init__(self, params):
+        params = [p for p in params]
+        if not params:
+            raise ValueError("Arena: empty parameter list")
+        dev = params[0].device
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("Arena: all parameters must be fp32 on one device")
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.size = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(params, self.offsets):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p._rg_grad = self.flat_grad[o:o + n].view(p.shape)
+            p._rg_arena = self
+            p._rg_offset = o
+
+    def runs(self):
+        """[(start, end)] element ranges covering consecutive parameters whose .grad is the arena view."""
+        out, cur = [], None
+        for p, o in zip(self.params, self.offsets):
+            ok = p.grad is not None and p.grad.data_ptr() == p._rg_grad.data_ptr()
+            end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if ok:
+                cur = [o, end] if cur is None else [cur[0], end]
+            elif cur is not None:
+                out.append(tuple(cur))
+                cur = None
+        if cur is not None:
+            out.append(tuple(cur))
+        return out
+
+
+def flatten_params(params):
+    return Arena(list(params))
+
+
+class _FlatOptimizer(Optimizer):
+    """One arena for ALL parameter groups (the ReID optimizer of the reference has one group per tensor,
+    SURVEY §9.12); launches are split only where hyper-parameters or step counts differ."""
+
+    def _setup(self):
+        ps = [p for g in self.param_groups for p in g["params"]]
+        owned = [getattr(p, "_rg_arena", None) for p in ps]
+        if any(a is not None for a in owned):
+            a = owned[0]
+            if a is None or any(o is not a for o in owned) or len(a.params) != len(ps) or \
+                    any(x is not y for x, y in zip(a.params, ps)):
+                raise ValueError("rg_hip.optim: parameters already belong to a different arena")
+            self._arena = a
+        else:
+            self._arena = Arena(ps)
+        self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
+
+    def _adopt_foreign_grads(self):
+        for p in self._arena.params:        # gradients set by hand / by stock autograd: copy into the arena
+            if p.grad is not None and p.grad.data_ptr() != p._rg_grad.data_ptr():
+                p._rg_grad.copy_(p.grad)
+                p.grad = p._rg_grad
+
+    def _segments(self, key_of):
+        """maximal runs of consecutive parameters that have a gradient and share key_of(i): (a0, a1, [i...])"""
+        a = self._arena
+        segs, cur = [], None
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if p.grad is None:
+                cur = None
+                continue
+            k = key_of(i)
+            if cur is not None and cur[3] == k:
+                cur[1] = end
+                cur[2].append(i)
+            else:
+                cur = [o, end, [i], k]
+                segs.append(cur)
+        return segs
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._arena.params:
+            p.grad = None
+
+
+class Adam(_FlatOptimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_scale=1.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super(Adam, self).__init__(params, defaults)
+        self.grad_scale = grad_scale
+        self._setup()
+        self._m = torch.zeros_like(self._arena.flat)
+        self._v = torch.zeros_like(self._arena.flat)
+        self._steps = [0] * len(self._arena.params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._adopt_foreign_grads()
+        a, groups = self._arena, self.param_groups
+
+        def key_of(i):
+            g = groups[self._group_of[i]]
+            return (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[i])
+        for a0, a1, members, (lr, b1, b2, eps, wd, st) in self._segments(key_of):
+            ops.adam_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._m[a0:a1], self._v[a0:a1], lr, b1, b2, eps, wd,
+                          st + 1, self.grad_scale)
+            for i in members:
+                self._steps[i] += 1
+        return loss
+
+
+class SGD(_FlatOptimizer):
+    def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False, grad_scale=1.0):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError("rg_hip.optim.SGD: dampening / nesterov are not used by the reference")
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super(SGD, self).__init__(params, defaults)
+        self.grad_scale = grad_scale
+        self._setup()
+        self._buf = torch.zeros_like(self._arena.flat)
+        self._started = [False] * len(self._arena.params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._adopt_foreign_grads()
+        a, groups = self._arena, self.param_groups
+
+        def key_of(i):
+            g = groups[self._group_of[i]]
+            return (g["lr"], g["momentum"], g["weight_decay"], self._started[i])
+        for a0, a1, members, (lr, mom, wd, started) in self._segments(key_of):
+            ops.sgd_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._buf[a0:a1], lr, mom, wd, not started, self.grad_scale)
+            for i in members:
+                self._started[i] = True
+        return loss

@@ -1,0 +1,109 @@
+"""Data parallelism, MI355X style: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference's only multi-GPU mechanism is single-process torch.nn.DataParallel (FD/fdgan/model.py:67-70,
+CC/examples/cluster_contrast_gan_train_usl_infomap.py:197), which re-broadcasts every parameter on every
+forward call and reduces gradients onto GPU 0.  Here every rank owns a full replica; after (and
+overlapped with) each backward pass the gradient ARENA of an optimizer (rg_hip.optim.Arena.flat_grad) is
+all-reduced in place — no bucket copy-in/copy-out because weight gradients were written contiguously —
+in chunks of `bucket_mb` on the process group's side stream, and the 1/world averaging is folded into
+the fused optimizer kernel (`grad_scale`).
+
+`DataParallel` is an API shim: it keeps the `.module` attribute and the `module.` state_dict prefix the
+reference's scripts and checkpoints rely on (FD/train.py:57, FD/fdgan/networks.py:51-55).
+"""
+from __future__ import absolute_import
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, device_ids=None, output_device=None, dim=0):
+        super(DataParallel, self).__init__()
+        self.module = module
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradReducer(object):
+    """All-reduce (sum) of an optimizer's gradient arena; averaging happens in the optimizer kernel."""
+
+    def __init__(self, optimizer, bucket_mb=64, group=None):
+        self.optimizer = optimizer
+        self.arena = getattr(optimizer, "_arena", None)
+        self.group = group
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self._pending = []
+        self._done = []          # element ranges already launched in this round
+        if self.arena is not None and world_size() > 1:
+            optimizer.grad_scale = 1.0 / world_size()
+
+    def active(self):
+        return self.arena is not None and world_size() > 1
+
+    def _ranges_for(self, params):
+        a = self.arena
+        if params is None:
+            idx = range(len(a.params))
+        else:
+            ids = {id(p) for p in params}
+            idx = [i for i, p in enumerate(a.params) if id(p) in ids]
+        out, cur = [], None
+        for i in idx:
+            p, o = a.params[i], a.offsets[i]
+            if p.grad is None or p.grad.data_ptr() != p._rg_grad.data_ptr():
+                cur = None
+                continue
+            end = o + p.numel()
+            if any(s <= o < e for s, e in self._done):
+                cur = None
+                continue
+            if cur is not None and o - cur[1] < 64 + 1 and o >= cur[1]:
+                cur[1] = end
+            else:
+                cur = [o, end]
+                out.append(cur)
+        return [(s, e) for s, e in out]
+
+    def reduce_async(self, params=None):
+        """Launch the all-reduce of the gradients of `params` (default: everything not launched yet).
+        Returns immediately; the collective runs on the process group's stream after the work already
+        queued on the current stream."""
+        if not self.active():
+            return
+        for s, e in self._ranges_for(params):
+            self._done.append((s, e))
+            pos = s
+            while pos < e:
+                end = min(e, pos + self.bucket_elems)
+                work = dist.all_reduce(self.arena.flat_grad[pos:end], op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
+                self._pending.append(work)
+                pos = end
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._done = []
+
+    def reduce(self):
+        self.reduce_async(None)
+        self.wait()
+
+
+def all_gather_rows(x, group=None):
+    """[B_local, D] -> [world * B_local, D] in rank order (features / labels for the ClusterMemory update,
+    so that every rank applies the identical sequential centroid update)."""
+    w = world_size()
+    if w == 1:
+        return x
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out

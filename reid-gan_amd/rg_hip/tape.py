@@ -20,13 +20,14 @@ from . import ops
 
 
 class Tape(object):
-    __slots__ = ("stack", "grads", "param_grad", "record")
+    __slots__ = ("stack", "grads", "param_grad", "record", "needs_input")
 
-    def __init__(self, param_grad=True, record=True):
+    def __init__(self, param_grad=True, record=True, needs_input=None):
         self.stack = []
         self.grads = {}
         self.param_grad = param_grad
         self.record = record
+        self.needs_input = needs_input        # per network input: does anything upstream want its gradient?
 
     def push(self, item):
         if self.record:
@@ -38,19 +39,33 @@ class Tape(object):
     def wants(self, p):
         return self.param_grad and p is not None and p.requires_grad
 
+    def grad_out(self, p):
+        """Arena view the FIRST gradient contribution of `p` may be written into directly (or None)."""
+        v = getattr(p, "_rg_grad", None)
+        if v is None or p.grad is not None or id(p) in self.grads:
+            return None
+        return v
+
     def add_grad(self, p, g):
         k = id(p)
         if g.shape != p.shape:
             g = g.view(p.shape)
         prev = self.grads.get(k)
-        self.grads[k] = g if prev is None else ops.add(prev, g)
+        if prev is None:
+            v = getattr(p, "_rg_grad", None)
+            if v is not None and p.grad is None and g.data_ptr() != v.data_ptr():
+                g = ops.axpby(g, None, 1.0, 0.0, out=v)           # move into the arena
+            self.grads[k] = g
+        else:
+            self.grads[k] = ops.axpby(prev, g, 1.0, 1.0, out=prev)
 
 
 class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, n_in, *tensors):
         xs, params = tensors[:n_in], tensors[n_in:]
-        tape = Tape(param_grad=len(params) > 0)
+        tape = Tape(param_grad=len(params) > 0,
+                    needs_input=[isinstance(x, torch.Tensor) and x.requires_grad for x in xs])
         ctx.set_materialize_grads(False)
         outs = net.tf(tape, *[x.detach() if isinstance(x, torch.Tensor) else x for x in xs])
         ctx.tape, ctx.net, ctx.params, ctx.n_in = tape, net, params, n_in
@@ -66,9 +81,22 @@ class _NetFn(torch.autograd.Function):
         if not isinstance(dxs, (tuple, list)):
             dxs = (dxs,)
         dxs = tuple(dxs) + (None,) * (n_in - len(dxs))
-        grads = tuple(tape.grads.get(id(p)) for p in ctx.params)
+        grads = []
+        for p in ctx.params:
+            g = tape.grads.get(id(p))
+            v = getattr(p, "_rg_grad", None)
+            if g is None or v is None:
+                grads.append(g)
+            elif g.data_ptr() == v.data_ptr():                    # written straight into the gradient arena
+                p.grad = v
+                grads.append(None)
+            elif p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                ops.axpby(v, g, 1.0, 1.0, out=v)                  # accumulate across backward calls
+                grads.append(None)
+            else:
+                grads.append(g)
         ctx.tape = None
-        return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + grads
+        return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + tuple(grads)
 
 
 def run(net, *xs):

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI boundary — the shared library loads, exports every symbol include/reidgan_hip.h declares,
+rejects bad arguments with a message, and the Python host refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+
+from rg_hip import lib as L
+from rg_hip import ops
+
+
+def test_header_parses_and_library_exports_every_symbol():
+    protos = L.parse_header()
+    assert len(protos) >= 45
+    assert os.path.exists(L.LIB_PATH), "build with __graft_entry__.build() first"
+    dll = ctypes.CDLL(L.LIB_PATH)
+    missing = [n for n in protos if not hasattr(dll, n)]
+    assert not missing, missing
+    # and nothing exported by the library is undocumented in the header
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], stdout=subprocess.PIPE,
+                         universal_newlines=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T rg_" in ln}
+    assert exported <= set(protos), exported - set(protos)
+
+
+def test_queries_and_error_convention_without_gpu():
+    lib = L.lib
+    assert lib.rg_version() >= 1
+    assert lib.rg_family_count() == len(L.FAMILIES)
+    assert lib.rg_loss_workspace() >= 1024
+    assert lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32) > 0
+    with pytest.raises(RuntimeError) as e:
+        lib.rg_fill(None, 4, 1.0, None)
+    assert "rg_fill" in str(e.value)
+    with pytest.raises(RuntimeError) as e:       # inconsistent geometry is rejected before any launch
+        lib.rg_conv2d_fwd(1, 1, 1, 1, 3, 8, 8, 4, 3, 3, 1, 1, 1, 1, 99, 99, None, None, None, 0, 0.0, None)
+    assert "rg_conv2d_fwd" in str(e.value)
+
+
+def test_host_refuses_cpu_tensors():
+    x = torch.randn(1, 3, 8, 8)
+    w = torch.randn(4, 3, 3, 3)
+    with pytest.raises(RuntimeError) as e:
+        ops.conv2d_fwd(x, w, 1, 1)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    fresh = L._Lib()
+    with pytest.raises(ImportError):
+        fresh.load()
+
+
+def test_state_dict_layout_matches_reference_keys():
+    """Checkpoint compatibility: parameter names/shapes equal the oracle's (== the reference's) modules."""
+    from oracle import ref_torch as O
+    import fdgan.networks as N
+    import reid.models as RM
+    from reid.models.embedding import EltwiseSubEmbed
+    from reid.models.multi_branch import SiameseNet
+
+    def same(a, b):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        for k in sa:
+            assert sa[k].shape == sb[k].shape, k
+
+    same(N.CustomPoseGenerator(128, 2048, 256, dropout=0.2, norm_layer=N.get_norm_layer('batch')),
+         O.OPoseGenerator(128, 2048, 256, dropout=0.2))
+    same(N.CustomPoseGenerator(128, 2048, 256, norm_layer=N.get_norm_layer('batch'), connect_layers=3),
+         O.OPoseGenerator(128, 2048, 256, connect_layers=3))
+    same(N.NLayerDiscriminator(21, norm_layer=N.get_norm_layer('batch')), O.OPatchDiscriminator(21))
+    same(N.NLayerDiscriminator(21, norm_layer=N.get_norm_layer('instance')), O.OPatchDiscriminator(21, 'instance'))
+    e = SiameseNet(RM.create('resnet50', pretrained=False, cut_at_pooling=True),
+                   EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=2))
+    oe = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True),
+                       O.OEltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=2))
+    same(e, oe)
+    assert "base_model.base.fc.weight" in e.state_dict()       # the unused fc stays in checkpoints
+    with pytest.raises(KeyError):
+        RM.create('resnet51')
