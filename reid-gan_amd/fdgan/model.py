@@ -168,7 +168,7 @@ class FDGANModel(object):
         labels = (input1['pid'] == input2['pid']).long()
         noise = input1.get('noise') if isinstance(input1, dict) else None     # tests feed z explicitly
         if noise is None:
-            noise = torch.randn(labels.size(0), self.opt.noise_feature_size)
+            noise = torch.randn(labels.size(0), self.opt.noise_feature_size, device=labels.device)
 
         # keep the same pose map for persons with the same identity
         mask = labels.view(-1, 1, 1, 1).expand_as(input1['posemap'])
