@@ -110,3 +110,22 @@ def weighted_mean(x, w=None):
 def cross_entropy(logits, labels, scale=1.0):
     """F.cross_entropy(logits * scale, labels) (mean reduction)."""
     return weighted_mean(cross_entropy_rows(logits, labels, scale))
+
+
+class _L2NormRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, nrm = ops.l2norm_rows_fwd(x, eps)
+        ctx.save_for_backward(y, nrm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, nrm = ctx.saved_tensors
+        return ops.l2norm_rows_bwd(y, g, nrm, ctx.eps), None
+
+
+def normalize_rows(x, eps=1e-12):
+    """F.normalize(x, dim=1) for a [rows, D] tensor."""
+    return _L2NormRows.apply(x, eps)

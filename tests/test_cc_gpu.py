@@ -1,0 +1,165 @@
+"""Cluster-contrast path on the MI355X vs the oracle: encoder (layer4 stride 1, GeM, feat_bn), ClusterMemory
+(logits, per-sample loss, input gradient with the PRE-update bank, ordered momentum update with repeated labels,
+hard variant) and the ClusterContrastTrainer step."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_modules_gpu import _check, _check_anchored, _check_grads_anchored, _check_l2, _rel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cluster_memory(dev):
+    from oracle import ref_torch as O
+    from clustercontrast.models.cm import ClusterMemory
+    g = torch.Generator().manual_seed(1)
+    K, D, B = 2048, 2048, 64
+    bank = F.normalize(torch.randn(K, D, generator=g), dim=1)
+    x = torch.randn(B, D, generator=g) * 2
+    ids = torch.randint(0, K, (4,), generator=g)
+    labels = ids.repeat_interleave(16)[torch.randperm(B, generator=g)]        # 4 identities x 16 instances
+    for hard in (False, True):
+        om = O.OClusterMemory(D, K, temp=0.05, momentum=0.2, use_hard=hard)
+        om.features = bank.clone()
+        rm = ClusterMemory(D, K, temp=0.05, momentum=0.2, use_hard=hard).to(dev)
+        rm.features = bank.clone().to(dev)                    # callers re-assign the buffer every epoch
+        xo = x.clone().requires_grad_(True)
+        xr = x.clone().to(dev).requires_grad_(True)
+        lo, lr = om(xo, labels), rm(xr, labels.to(dev))
+        assert lr.shape == (B,)
+        _check(lr, lo, 1e-4, "per-sample loss hard=%s" % hard)
+        lo.mean().backward()
+        lr.mean().backward()
+        _check(xr.grad, xo.grad, 1e-4, "grad_inputs hard=%s" % hard)
+        _check(rm.features, om.features, 1e-5, "bank after update hard=%s" % hard)
+        assert not torch.equal(rm.features.cpu(), bank)
+
+
+def test_cc_functions_api(dev):
+    """cm()/cm_hard() keep the reference signature, including a tensor-valued momentum."""
+    from oracle import ref_torch as O
+    from clustercontrast.models import cm as M
+    from tests.golden import cases as C
+    bank, feats, labels, gout = C.cm_case()
+    for fn, ofn in ((M.cm, O.OCM), (M.cm_hard, O.OCMHard)):
+        bo, br = bank.clone(), bank.clone().to(dev)
+        xo, xr = feats.clone().requires_grad_(True), feats.clone().to(dev).requires_grad_(True)
+        yo = ofn.apply(xo, labels, bo, torch.Tensor([0.2]))
+        yr = fn(xr, labels.to(dev), br, torch.Tensor([0.2]).to(dev))
+        yo.backward(gout)
+        yr.backward(gout.to(dev))
+        _check(yr, yo, 1e-5, "logits")
+        _check(xr.grad, xo.grad, 1e-5, "grad")
+        _check(br, bo, 1e-5, "bank")
+
+
+def _cc_pair(O, dev, pooling):
+    import clustercontrast.models as M
+    torch.manual_seed(3)
+    o = O.OCCResNet(50, pooling_type=pooling)
+    r = M.create('resnet50', pretrained=False, pooling_type=pooling)
+    r.load_state_dict(o.state_dict())
+    return o, r.to(dev)
+
+
+@pytest.mark.parametrize("pooling", ["gem", "avg"])
+def test_cc_encoder(dev, pooling):
+    from oracle import ref_torch as O
+    o, r = _cc_pair(O, dev, pooling)
+    x = O.synth_images(8, 128, 64, seed=4)
+    # eval: L2-normalised embedding
+    o.eval()
+    r.eval()
+    with torch.no_grad():
+        _check(r(x.to(dev)), o(x), 1e-3, "eval embedding")
+    # train: tuple (bn_x, normalised map), gradients anchored on fp64 (train-mode BN, tiny batch)
+    o.train()
+    r.train()
+    o64 = O.OCCResNet(50, pooling_type=pooling)
+    o64.load_state_dict(o.state_dict())
+    o64 = o64.double().train()
+    bo, go = o(x)
+    br, gr = r(x.to(dev))
+    b64, _ = o64(x.double())
+    _check(br, bo, 1e-3, "bn_x")
+    _check(gr, go, 1e-3, "normalised map")
+    gen = torch.Generator().manual_seed(5)
+    g = torch.randn(bo.shape, generator=gen)
+    bo.backward(g)
+    br.backward(g.to(dev))
+    b64.backward(g.double())
+    _check_grads_anchored(r, o, o64, "cc encoder " + pooling)
+    assert r.feat_bn.bias.grad is None                      # frozen bias (resnet.py:61)
+
+
+def _trainer_pair(O, dev, depth):
+    import clustercontrast.models as M
+    import reid.models as RM
+    from clustercontrast.models.cm import ClusterMemory
+    torch.manual_seed(3)
+    if depth >= 50:
+        o = O.OCCResNet(depth, pooling_type="gem")
+        r = M.create('resnet%d' % depth, pretrained=False, pooling_type="gem")
+    else:
+        # the cluster-contrast wrapper's stride edit (resnet.py:34-35) only fits Bottleneck depths — with a
+        # BasicBlock trunk the reference itself fails with a shape mismatch — so the shallow encoder for the
+        # multi-step trainer test is the FD-GAN ReID wrapper (any encoder works with the trainer)
+        o = O.OReidResNet(depth)
+        r = RM.create('resnet%d' % depth, pretrained=False)
+    r.load_state_dict(o.state_dict())
+    r.to(dev).train()
+    o.train()
+    D = o.num_features
+    K = 64
+    g = torch.Generator().manual_seed(6)
+    bank = F.normalize(torch.randn(K, D, generator=g), dim=1)
+    om = O.OClusterMemory(D, K, temp=0.05, momentum=0.1)
+    om.features = bank.clone()
+    rm = ClusterMemory(D, K, temp=0.05, momentum=0.1).to(dev)
+    rm.features = bank.clone().to(dev)
+    return o, r, om, rm, g, K
+
+
+def _per_tensor_adam(net, cls):
+    # the reference builds one Adam group per tensor (examples/cluster_contrast_gan_train_usl_infomap.py:281-284)
+    return cls([{"params": [p]} for p in net.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+
+
+def test_cc_trainer_step_resnet50(dev):
+    """First ClusterContrastTrainer step at the real depth: loss and updated bank within 1e-3.
+    (Later steps of a randomly initialised train-mode-BN ResNet-50 at batch 16 are chaotic inside the reference
+    itself: its own fp32 CPU run moves by 0.3 % in the step-2 loss when only the thread count changes and by 1.1 %
+    in the step-1 loss under a 1e-6 input perturbation, so multi-step trajectories are checked on the
+    well-conditioned ResNet-18 below.)"""
+    from oracle import ref_torch as O
+    from clustercontrast.trainers import ClusterContrastTrainer
+    from rg_hip import optim as roptim
+    o, r, om, rm, g, K = _trainer_pair(O, dev, 50)
+    oopt, ropt = _per_tensor_adam(o, torch.optim.Adam), _per_tensor_adam(r, roptim.Adam)
+    trainer = ClusterContrastTrainer(r, rm)
+    x = O.synth_images(16, 128, 64, seed=10)
+    labels = torch.randint(0, K, (4,), generator=g).repeat_interleave(4)
+    lo = O.o_cc_step(o, om, oopt, x, labels)
+    lr = trainer.step(x.to(dev), labels.to(dev), ropt).item()
+    assert abs(lr - lo) <= 1e-3 * abs(lo), (lr, lo)
+    _check_l2(rm.features, om.features, 1e-3, "bank after step 0")
+
+
+def test_cc_trainer_three_steps(dev):
+    """Three consecutive steps (forward, CM backward + ordered bank update, per-tensor-group Adam with weight
+    decay) on ResNet-18, whose gradients are well conditioned in fp32: per-step loss within 1e-3."""
+    from oracle import ref_torch as O
+    from clustercontrast.trainers import ClusterContrastTrainer
+    from rg_hip import optim as roptim
+    o, r, om, rm, g, K = _trainer_pair(O, dev, 18)
+    oopt, ropt = _per_tensor_adam(o, torch.optim.Adam), _per_tensor_adam(r, roptim.Adam)
+    trainer = ClusterContrastTrainer(r, rm)
+    for it in range(3):
+        x = O.synth_images(16, 128, 64, seed=10 + it)
+        labels = torch.randint(0, K, (4,), generator=g).repeat_interleave(4)
+        lo = O.o_cc_step(o, om, oopt, x, labels)
+        lr = trainer.step(x.to(dev), labels.to(dev), ropt).item()
+        assert abs(lr - lo) <= 1e-3 * abs(lo), "step %d loss %r vs %r" % (it, lr, lo)
+        # the rows written into the bank are features of weights that went through `it` Adam steps
+        _check_l2(rm.features, om.features, 1e-3 if it == 0 else 3e-3, "bank after step %d" % it)
