@@ -58,12 +58,22 @@ int rg_profile_collect(double* ms, double* flops, double* bytes, long long* call
  * scale/shift/residual may be NULL. dgrad computes dx from dy (== ConvTranspose2d forward with
  * dy as its input and dx[N][C][H][W] as its output; epilogue indexed by c). Stride <= 2 for dgrad.
  */
-int rg_conv2d_fwd(const float* x, const float* w, float* y, int N, int C, int H, int W, int K, int KH, int KW, int SH,
-                  int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift, const float* residual,
-                  int act, float slope, rg_stream_t stream);
-int rg_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W, int K, int KH, int KW,
-                    int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
-                    const float* residual, int act, float slope, rg_stream_t stream);
+size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
+/* w_krsc (optional, may be NULL): the weights re-laid out as [K][KH*KW][C] by rg_weights_to_krsc.  With it the
+ * kernels walk the reduction (r,s)-major, so the padding test of the pixel gather happens once per 16-deep k-tile
+ * (fwd, C % 16 == 0) and the weight operand of the data gradient is contiguous (float4 loads; K % 16 == 0,
+ * C % 4 == 0); NULL selects the generic loaders.  Workspace: split-K scratch for layers too small to fill the chip
+ * (dgrad: stride 1 only); a too-small workspace just disables the split.  Every tensor must be < 2 GiB. */
+int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y, int N, int C, int H, int W, int K,
+                  int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
+                  const float* residual, int act, float slope, void* workspace, size_t workspace_bytes,
+                  rg_stream_t stream);
+size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW);
+int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K,
+                    int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
+                    const float* shift, const float* residual, int act, float slope, void* workspace,
+                    size_t workspace_bytes, rg_stream_t stream);
+int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, rg_stream_t stream);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,

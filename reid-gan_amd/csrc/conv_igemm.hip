@@ -12,6 +12,15 @@
 //   dgrad : dx[C, N*Hc*Wc]   = w^T[C, K*taps]         x gather(dy)[K*taps, N*Hc*Wc]   per stride-parity class
 //   wgrad : dw[K, C*KH*KW]   = dy[K, N*P*Q]           x im2col(x)^T[N*P*Q, C*KH*KW]   split over N*P*Q
 //
+// Loader variants (chosen on the host from the geometry):
+//   * the reduction index k is wave-uniform in the gather loaders, so its (c,r,s) / (k,tap) decomposition runs on
+//     the scalar unit (one readfirstlane); per lane only the bounds test and the address add remain;
+//   * 1x1 / stride 1 / pad 0 layers (half of ResNet-50) load the pixel operand as float4 (16 B per lane);
+//   * dgrad reads weights re-laid out as [K][KH*KW][C] (rg_weights_to_krsc, one tiny pass per layer per step) so the
+//     weight operand is contiguous along the GEMM row and loads as float4 as well;
+//   * layers whose M x N tile count cannot fill 256 CUs (8x4 and 16x8 maps at batch 32) split the reduction over
+//     blockIdx.y; partial tiles go to a workspace and a finishing kernel sums them and applies the epilogue.
+//
 // Work decomposition: 256-thread workgroup = 4 wave64; block tile BM x BN x 16, each wave owns a
 // (BM/WM) x (BN/WN) sub-tile made of 32x32 MFMA tiles.  Operand tiles are staged global -> VGPR ->
 // LDS, k-major ([16][BM+4] / [16][BN+4]) so that the MFMA operand reads (lane = row, lane>>5 = k)
@@ -19,6 +28,9 @@
 // next tile's global loads are issued before the current tile's MFMAs.  The flat tile id is
 // remapped so that every XCD (private 4 MiB L2) works on a contiguous range of pixel tiles.
 #include "rg_common.h"
+
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -72,8 +84,12 @@ struct ConvP {
     int a_vec4;
     int m_tiles, n_tiles;
     FastDiv d_rs, d_kw, d_pq, d_q;
-    // wgrad
+    // split-K (fwd / dgrad: partial tiles to `partial`; wgrad: to y)
     int ktiles_per_split, splits;
+    float* partial;
+    // buffer-resource sizes (bytes, < 2^31) of x / w / y / partial, and extra dividers for the (r,s)-major orders
+    unsigned x_bytes, w_bytes, y_bytes, partial_bytes;
+    FastDiv d_c, d_k;
 };
 
 struct DgradClass {
@@ -130,146 +146,92 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
-    using T = Tile<BM, BN, WM, WN>;
-    __shared__ float As[2][BK][T::LDA];
-    __shared__ float Bs[2][BK][T::LDB];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid % WN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+// ---- raw buffer access: 32-bit byte offsets from a wave-uniform base, hardware range check (a load beyond
+// num_records returns 0, a store is dropped).  An invalid lane simply carries OOB as its offset: no branches.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef int int4v __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;      // every tensor is < 2^31 bytes (checked on the host)
 
-    // B (im2col gather): fixed pixel column per thread, lanes run along pixels (coalesced rows)
-    constexpr int BKSTEP = NT / BN > 0 ? NT / BN : 1;
-    const int bcol = tid % BN, bk0 = tid / BN;
-    const int n = n0 + bcol;
-    const bool bvalid = n < p.Ng;
-    int img = 0, h0 = 0, w0 = 0;
-    if (bvalid) {
-        img = fdiv(n, p.d_pq);
-        const int pq = n - img * p.P * p.Q;
-        const int pp = fdiv(pq, p.d_q);
-        const int qq = pq - pp * p.Q;
-        h0 = pp * p.SH - p.PH;
-        w0 = qq * p.SW - p.PW;
-    }
-    const int HW = p.H * p.W;
-    const float* xb = p.x + (int64_t)img * p.C * HW;
-    const int pix_off = h0 * p.W + w0;
-    const int RS = p.KH * p.KW;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float4 bload4(rsrc_t r, unsigned off) {
+    // bit_cast of the builtin's own 16-byte vector type (an implicit conversion to an ext_vector splats lane 0)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void bstore(rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+}
 
-    float ra[T::ACNT], rb[T::BCNT];
-    floatx16 acc[T::TM][T::TN];
+template <typename T>
+__device__ __forceinline__ void zero_acc(floatx16 (&acc)[T::TM][T::TN]) {
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int j = 0; j < T::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
 
-    auto load_tile = [&](int kt) {
-        const int kbase = kt * BK;
-        // A: weights [M][Kg], contiguous along k
-        if (p.a_vec4) {
+// Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
+// With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] instead.  Buffer stores: one VALU add per
+// element, lanes outside the tensor carry OOB and are dropped by the hardware.
+template <typename T>
+__device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
+                                                int wm, int wn, int lane, int Ng, int PIX, const FastDiv& d_pix,
+                                                int split) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+    const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && p.ep.act == RG_ACT_NONE;
+    if (p.partial || plain) {
+        const rsrc_t ro = p.partial ? make_rsrc(p.partial, p.partial_bytes) : make_rsrc(p.y, p.y_bytes);
+        const unsigned rstride = (p.partial ? (unsigned)Ng : (unsigned)PIX) * 4u;    // bytes between GEMM rows
 #pragma unroll
-            for (int i = 0; i < T::ACNT / 4; ++i) {
-                const int v = tid + NT * i;
-                const int row = v >> 2, kq = (v & 3) * 4;
-                const int m = m0 + row, k = kbase + kq;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < BM * 4 && m < p.M && k < p.Kg)
-                    t = *reinterpret_cast<const float4*>(p.w + (int64_t)m * p.Kg + k);
-                ra[4 * i + 0] = t.x;
-                ra[4 * i + 1] = t.y;
-                ra[4 * i + 2] = t.z;
-                ra[4 * i + 3] = t.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < T::ACNT; ++i) {
-                const int e = tid + NT * i;
-                const int kk = e & 15, row = e >> 4;
-                const int m = m0 + row, k = kbase + kk;
-                ra[i] = (e < BM * BK && m < p.M && k < p.Kg) ? p.w[(int64_t)m * p.Kg + k] : 0.f;
-            }
-        }
-        // B: gather
-#pragma unroll
-        for (int i = 0; i < T::BCNT; ++i) {
-            const int kk = bk0 + i * BKSTEP;
-            const int k = kbase + kk;
-            const int c = fdiv(k, p.d_rs);
-            const int rs = k - c * RS;
-            const int r = fdiv(rs, p.d_kw);
-            const int s = rs - r * p.KW;
-            const int h = h0 + r, w = w0 + s;
-            const bool ok = bvalid && k < p.Kg && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            rb[i] = ok ? xb[c * HW + r * p.W + s + pix_off] : 0.f;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        if (p.a_vec4) {
-#pragma unroll
-            for (int i = 0; i < T::ACNT / 4; ++i) {
-                const int v = tid + NT * i;
-                const int row = v >> 2, kq = (v & 3) * 4;
-                if (v < BM * 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) As[buf][kq + j][row] = ra[4 * i + j];
+        for (int j = 0; j < T::TN; ++j) {
+            const int nn = n0 + wn * T::WTN + j * 32 + l32;
+            unsigned ob = OOB;
+            if (nn < Ng) {
+                if (p.partial) {
+                    ob = (unsigned)(((split * p.M + mrow0) * (int64_t)Ng + nn) * 4);
+                } else {
+                    const int im = fdiv(nn, d_pix);
+                    ob = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
                 }
             }
-        } else {
 #pragma unroll
-            for (int i = 0; i < T::ACNT; ++i) {
-                const int e = tid + NT * i;
-                const int kk = e & 15, row = e >> 4;
-                if (e < BM * BK) As[buf][kk][row] = ra[i];
-            }
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned off = (mrow0 + mo < p.M) ? ob + (unsigned)mo * rstride : OOB;
+                    bstore(ro, off, acc[i][j][r]);
+                }
         }
-#pragma unroll
-        for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
-    };
-
-    const int nk = (p.Kg + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool has_next = kt + 1 < nk;
-        if (has_next) load_tile(kt + 1);
-        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
-        if (has_next) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        return;
     }
-
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int l32 = lane & 31, kh = lane >> 5;
-    const int PQ = p.P * p.Q;
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int nn = n0 + wn * T::WTN + j * 32 + l32;
-        if (nn >= p.Ng) continue;
-        const int im = fdiv(nn, p.d_pq);
-        const int pq = nn - im * PQ;
-        const int64_t obase = (int64_t)im * p.K * PQ + pq;
+        if (nn >= Ng) continue;
+        const int im = fdiv(nn, d_pix);
+        const int pix = nn - im * PIX;
+        const int64_t obase = (int64_t)im * p.M * PIX + pix;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (m < p.M) {
                     float v = acc[i][j][r];
                     if (p.ep.scale) v *= p.ep.scale[m];
                     if (p.ep.shift) v += p.ep.shift[m];
-                    const int64_t o = obase + (int64_t)m * PQ;
+                    const int64_t o = obase + (int64_t)m * PIX;
                     if (p.ep.res) v += p.ep.res[o];
                     p.y[o] = rg_apply_act(v, p.ep.act, p.ep.slope);
                 }
@@ -278,14 +240,196 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
     }
 }
 
+// A operand loader shared by fwd (weights [M][Kg], k contiguous): float4 along k (AVEC) or scalar.
+template <int BM, bool AVEC>
+struct ALoadK {
+    static constexpr int NA = AVEC ? ((BM * 4 + NT - 1) / NT) : (BM * BK / NT);
+    unsigned off[NA];
+    int kq[NA];
+    __device__ __forceinline__ void init(int tid, int m0, int M, int Kg) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + NT * i;
+            const int row = AVEC ? (v >> 2) : (v >> 4);
+            kq[i] = AVEC ? (v & 3) * 4 : (v & 15);
+            const bool ok = (AVEC ? v < BM * 4 : v < BM * BK) && (m0 + row < M);
+            off[i] = ok ? (unsigned)(((int64_t)(m0 + row) * Kg + kq[i]) * 4) : OOB;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
-// data gradient (also the forward of ConvTranspose2d), one GEMM per stride-parity class
+// forward.  BMODE 0: generic gather, reduction order (c, r, s), weights [K][C][KH][KW]
+//           BMODE 1: (r, s)-major order k' = rs*C + c, weights [K][KH*KW][C], C % 16 == 0: one bounds test per tile
+//           BMODE 2: 1x1 / stride 1 / pad 0 with H*W % 4 == 0: pixel operand as float4
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC>
+__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
+    using T = Tile<BM, BN, WM, WN>;
+    static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][T::LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int split = blockIdx.y;
+    const int HW = p.H * p.W;
+    const int RS = p.KH * p.KW;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+
+    ALoadK<BM, AVEC> al;
+    al.init(tid, m0, p.M, p.Kg);
+
+    // ---- B operand set-up ----
+    constexpr int BKSTEP = NT / BN > 0 ? NT / BN : 1;
+    const int bcol = tid % BN;
+    const int bk0 = __builtin_amdgcn_readfirstlane(tid / BN);
+    constexpr int BV = BN / 4;
+    constexpr int BVSTEP = NT / BV;
+    constexpr int BVCNT = (BV * BK + NT - 1) / NT;
+    const int vcol = tid % BV, vrow0 = tid / BV;
+
+    bool bvalid;
+    int h0 = 0, w0 = 0, pixb = 0;     // pixb: element index of (img, c=0, h0, w0); may be "negative" inside padding
+    unsigned bvoff = OOB;             // BMODE 2: byte offset of (img, k = vrow0, pix)
+    if (BMODE == 2) {
+        const int n = n0 + 4 * vcol;
+        bvalid = n < p.Ng && vrow0 < BK;
+        if (bvalid) {
+            const int img = fdiv(n, p.d_pq);
+            bvoff = (unsigned)((((int64_t)img * p.C + vrow0) * HW + (n - img * HW)) * 4);
+        }
+    } else {
+        const int n = n0 + bcol;
+        bvalid = n < p.Ng;
+        if (bvalid) {
+            const int img = fdiv(n, p.d_pq);
+            const int pq = n - img * p.P * p.Q;
+            const int pp = fdiv(pq, p.d_q);
+            const int qq = pq - pp * p.Q;
+            h0 = pp * p.SH - p.PH;
+            w0 = qq * p.SW - p.PW;
+            pixb = img * p.C * HW + h0 * p.W + w0;
+        }
+    }
+
+    float ra[AVEC ? 4 * ALoadK<BM, AVEC>::NA : ALoadK<BM, AVEC>::NA];
+    float rb[BMODE == 2 ? 1 : T::BCNT];
+    float4 rbv[BMODE == 2 ? BVCNT : 1];
+    floatx16 acc[T::TM][T::TN];
+    zero_acc<T>(acc);
+
+    auto load_tile = [&](int kt) {
+        const int kbase = kt * BK;
+        const unsigned kb4 = (unsigned)kbase * 4u;
+        const bool ktail = kbase + BK > p.Kg;                    // uniform; only the last tile of ragged Kg
+#pragma unroll
+        for (int i = 0; i < ALoadK<BM, AVEC>::NA; ++i) {
+            unsigned o = al.off[i] + kb4;
+            if (ktail && kbase + al.kq[i] >= p.Kg) o = OOB;
+            if (AVEC) {
+                const float4 t = bload4(rw, o);
+                ra[4 * i + 0] = t.x; ra[4 * i + 1] = t.y; ra[4 * i + 2] = t.z; ra[4 * i + 3] = t.w;
+            } else {
+                ra[i] = bload(rw, o);
+            }
+        }
+        if (BMODE == 2) {
+            const unsigned kstride = (unsigned)HW * 4u;
+#pragma unroll
+            for (int i = 0; i < BVCNT; ++i) {
+                unsigned o = bvoff + (unsigned)(kbase + i * BVSTEP) * kstride;
+                if (ktail && kbase + vrow0 + i * BVSTEP >= p.Kg) o = OOB;
+                rbv[i] = bload4(rx, o);
+            }
+        } else if (BMODE == 1) {
+            const int rs = fdiv(kbase, p.d_c);                   // scalar: the whole tile shares (r, s)
+            const int c0 = kbase - rs * p.C;
+            const int r = fdiv(rs, p.d_kw);
+            const int s = rs - r * p.KW;
+            const int h = h0 + r, w = w0 + s;
+            const bool ok = bvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            const unsigned o0 = ok ? (unsigned)(pixb + r * p.W + s + (c0 + bk0) * HW) * 4u : OOB;
+            const unsigned cstride = (unsigned)(BKSTEP * HW) * 4u;
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) rb[i] = bload(rx, o0 + (unsigned)i * cstride);
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) {
+                const int k = kbase + bk0 + i * BKSTEP;          // wave-uniform -> scalar unit
+                const int c = fdiv(k, p.d_rs);
+                const int rs = k - c * RS;
+                const int r = fdiv(rs, p.d_kw);
+                const int s = rs - r * p.KW;
+                const int h = h0 + r, w = w0 + s;
+                const bool ok = bvalid && k < p.Kg && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                rb[i] = bload(rx, ok ? (unsigned)(pixb + c * HW + r * p.W + s) * 4u : OOB);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ALoadK<BM, AVEC>::NA; ++i) {
+            const int v = tid + NT * i;
+            if (AVEC) {
+                const int row = v >> 2, kq = (v & 3) * 4;
+                if (v < BM * 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) As[buf][kq + j][row] = ra[4 * i + j];
+                }
+            } else {
+                if (v < BM * BK) As[buf][v & 15][v >> 4] = ra[i];
+            }
+        }
+        if (BMODE == 2) {
+#pragma unroll
+            for (int i = 0; i < BVCNT; ++i) {
+                const int kk = vrow0 + i * BVSTEP;
+                if (kk < BK) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
+        }
+    };
+
+    const int nk = (p.Kg + BK - 1) / BK;
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > nk) kt_end = nk;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool has_next = kt + 1 < kt_end;
+        if (has_next) load_tile(kt + 1);
+        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, p.Ng, p.P * p.Q, p.d_pq, split);
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient (also the forward of ConvTranspose2d), one GEMM per stride-parity class.
+// MODE 0: weights [K][C][KH][KW], reduction order (ko, tap), scalar loads (any geometry)
+// MODE 1: weights [K][KH*KW][C] (== the original tensor for 1x1), tap-major order k' = tap*K + ko, K % 16 == 0 and
+//         C % 4 == 0: weight operand float4 along C, one bounds test per tile for dy
+// MODE 2: MODE 1 layout + 1x1 / stride 1 / pad 0 with P*Q % 4 == 0: dy loads as float4 too (any K)
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
     using T = Tile<BM, BN, WM, WN>;
-    __shared__ float As[2][BK][T::LDA];
-    __shared__ float Bs[2][BK][T::LDB];
+    static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][T::LDB];
     const ConvP& p = dp.c;
     const int ci = blockIdx.z;
     const DgradClass& cl = dp.cls[ci];
@@ -298,83 +442,160 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-
-    // B: gather of dy, fixed pixel column per thread
-    constexpr int BKSTEP = NT / BN > 0 ? NT / BN : 1;
-    const int bcol = tid % BN, bk0 = tid / BN;
-    const int n = n0 + bcol;
-    const bool bvalid = n < cl.Ngc;
-    int img = 0, hb = 0, wb = 0;
-    if (bvalid) {
-        img = fdiv(n, cl.d_hw);
-        const int rem = n - img * cl.Hc * cl.Wc;
-        const int hc = fdiv(rem, cl.d_w);
-        const int wc = rem - hc * cl.Wc;
-        hb = (ah + p.SH * hc + p.PH - cl.r0) / p.SH;
-        wb = (aw + p.SW * wc + p.PW - cl.s0) / p.SW;
-    }
+    const int split = blockIdx.y;
     const int PQ = p.P * p.Q;
-    const float* dyb = p.x + (int64_t)img * p.K * PQ;
-    const int taps = cl.nrh * cl.nrw;
-
-    // A: weights w[ko][c][r][s] with GEMM row m = c: lanes run along c
-    constexpr int AKSTEP = NT / BM > 0 ? NT / BM : 1;
-    constexpr int ACNT = (BM * BK / NT) < 1 ? 1 : (BM * BK / NT);
-    const int acol = tid % BM, ak0 = tid / BM;
-    const int am = m0 + acol;
-    const bool avalid = am < p.M;
     const int RS = p.KH * p.KW;
+    const int taps = cl.nrh * cl.nrw;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rdy = make_rsrc(p.x, p.x_bytes);
 
-    float ra[ACNT], rb[T::BCNT];
+    // ---- B operand (dy) ----
+    constexpr int BKSTEP = NT / BN > 0 ? NT / BN : 1;
+    const int bcol = tid % BN;
+    const int bk0 = __builtin_amdgcn_readfirstlane(tid / BN);
+    constexpr int BV = BN / 4;
+    constexpr int BVSTEP = NT / BV;
+    constexpr int BVCNT = (BV * BK + NT - 1) / NT;
+    const int vcol = tid % BV, vrow0 = tid / BV;
+    bool bvalid;
+    int hb = 0, wb = 0, imgb = 0;
+    unsigned bvoff = OOB;
+    if (MODE == 2) {
+        const int n = n0 + 4 * vcol;
+        bvalid = n < cl.Ngc && vrow0 < BK;
+        if (bvalid) {
+            const int img = fdiv(n, cl.d_hw);
+            bvoff = (unsigned)((((int64_t)img * p.K + vrow0) * PQ + (n - img * PQ)) * 4);
+        }
+    } else {
+        const int n = n0 + bcol;
+        bvalid = n < cl.Ngc;
+        if (bvalid) {
+            const int img = fdiv(n, cl.d_hw);
+            const int rem = n - img * cl.Hc * cl.Wc;
+            const int hc = fdiv(rem, cl.d_w);
+            const int wc = rem - hc * cl.Wc;
+            hb = (ah + p.SH * hc + p.PH - cl.r0) / p.SH;
+            wb = (aw + p.SW * wc + p.PW - cl.s0) / p.SW;
+            imgb = img * p.K * PQ;
+        }
+    }
+
+    // ---- A operand (weights), GEMM row m = input channel c ----
+    constexpr int AKSTEP = NT / BM > 0 ? NT / BM : 1;
+    constexpr int ACNT0 = (BM * BK / NT) < 1 ? 1 : (BM * BK / NT);
+    const int acol = tid % BM, ak0 = tid / BM;
+    constexpr int AV = BM / 4;
+    constexpr int AVSTEP = NT / AV;
+    constexpr int AVCNT = (AV * BK + NT - 1) / NT;
+    const int avcol = tid % AV, avrow0 = tid / AV;
+    // MODE 1/2: byte offset of (row k' = avrow0, m) inside one tap block of the [K][RS][C] tensor, or OOB
+    const unsigned avoff = (MODE != 0 && m0 + 4 * avcol < p.M && avrow0 < BK)
+                               ? (unsigned)(((int64_t)avrow0 * RS * p.C + m0 + 4 * avcol) * 4) : OOB;
+
+    float ra[MODE == 0 ? ACNT0 : 1];
+    float4 rav[MODE == 0 ? 1 : AVCNT];
+    float rb[MODE == 2 ? 1 : T::BCNT];
+    float4 rbv[MODE == 2 ? BVCNT : 1];
     floatx16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<T>(acc);
 
     auto load_tile = [&](int kt) {
         const int kbase = kt * BK;
+        const bool ktail = kbase + BK > cl.Kgc;
+        if (MODE == 0) {
+            const int am = m0 + acol;
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i) {
-            const int k = kbase + ak0 + i * AKSTEP;
-            const int ko = fdiv(k, cl.d_taps);
-            const int t = k - ko * taps;
-            const int j = fdiv(t, cl.d_nrw);
-            const int jj = t - j * cl.nrw;
-            const int r = cl.r0 + p.SH * j, s = cl.s0 + p.SW * jj;
-            const bool ok = avalid && k < cl.Kgc;
-            ra[i] = ok ? p.w[((int64_t)ko * p.C + am) * RS + r * p.KW + s] : 0.f;
+            for (int i = 0; i < ACNT0; ++i) {
+                const int k = kbase + ak0 + i * AKSTEP;
+                const int ko = fdiv(k, cl.d_taps);
+                const int t = k - ko * taps;
+                const int j = fdiv(t, cl.d_nrw);
+                const int jj = t - j * cl.nrw;
+                const int r = cl.r0 + p.SH * j, s = cl.s0 + p.SW * jj;
+                const bool ok = am < p.M && k < cl.Kgc;
+                ra[i] = bload(rw, ok ? (unsigned)((((int64_t)ko * p.C + am) * RS + r * p.KW + s) * 4) : OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) {
+                const int k = kbase + bk0 + i * BKSTEP;          // wave-uniform -> scalar unit
+                const int ko = fdiv(k, cl.d_taps);
+                const int t = k - ko * taps;
+                const int j = fdiv(t, cl.d_nrw);
+                const int jj = t - j * cl.nrw;
+                const int pp = hb - j, qq = wb - jj;
+                const bool ok = bvalid && k < cl.Kgc && (unsigned)pp < (unsigned)p.P && (unsigned)qq < (unsigned)p.Q;
+                rb[i] = bload(rdy, ok ? (unsigned)(imgb + ko * PQ + pp * p.Q + qq) * 4u : OOB);
+            }
+            return;
         }
+        // tap-major order: the whole tile shares one filter tap (scalar decode)
+        const int tap = fdiv(kbase, p.d_k);
+        const int ko0 = kbase - tap * p.K;
+        const int j = fdiv(tap, cl.d_nrw);
+        const int jj = tap - j * cl.nrw;
+        const int rs = (cl.r0 + p.SH * j) * p.KW + cl.s0 + p.SW * jj;
+        {
+            const unsigned tbase = (unsigned)(((int64_t)ko0 * RS + rs) * p.C * 4);
+            const unsigned kstride = (unsigned)(AVSTEP * RS * p.C) * 4u;
 #pragma unroll
-        for (int i = 0; i < T::BCNT; ++i) {
-            const int k = kbase + bk0 + i * BKSTEP;
-            const int ko = fdiv(k, cl.d_taps);
-            const int t = k - ko * taps;
-            const int j = fdiv(t, cl.d_nrw);
-            const int jj = t - j * cl.nrw;
+            for (int i = 0; i < AVCNT; ++i) {
+                unsigned o = avoff + tbase + (unsigned)i * kstride;
+                if (ktail && kbase + avrow0 + i * AVSTEP >= cl.Kgc) o = OOB;
+                rav[i] = bload4(rw, o);
+            }
+        }
+        if (MODE == 2) {
+            const unsigned kstride = (unsigned)PQ * 4u;
+#pragma unroll
+            for (int i = 0; i < BVCNT; ++i) {
+                unsigned o = bvoff + (unsigned)(kbase + i * BVSTEP) * kstride;
+                if (ktail && kbase + vrow0 + i * BVSTEP >= cl.Kgc) o = OOB;
+                rbv[i] = bload4(rdy, o);
+            }
+        } else {
             const int pp = hb - j, qq = wb - jj;
-            const bool ok = bvalid && k < cl.Kgc && (unsigned)pp < (unsigned)p.P && (unsigned)qq < (unsigned)p.Q;
-            rb[i] = ok ? dyb[ko * PQ + pp * p.Q + qq] : 0.f;
+            const bool ok = bvalid && (unsigned)pp < (unsigned)p.P && (unsigned)qq < (unsigned)p.Q;
+            const unsigned o0 = ok ? (unsigned)(imgb + (ko0 + bk0) * PQ + pp * p.Q + qq) * 4u : OOB;
+            const unsigned kstride = (unsigned)(BKSTEP * PQ) * 4u;
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) rb[i] = bload(rdy, o0 + (unsigned)i * kstride);
         }
     };
     auto store_tile = [&](int buf) {
+        if (MODE == 0) {
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i) As[buf][ak0 + i * AKSTEP][acol] = ra[i];
+            for (int i = 0; i < ACNT0; ++i) As[buf][ak0 + i * AKSTEP][acol] = ra[i];
+        } else {
 #pragma unroll
-        for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
+            for (int i = 0; i < AVCNT; ++i) {
+                const int kk = avrow0 + i * AVSTEP;
+                if (kk < BK) *reinterpret_cast<float4*>(&As[buf][kk][4 * avcol]) = rav[i];
+            }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < BVCNT; ++i) {
+                const int kk = vrow0 + i * BVSTEP;
+                if (kk < BK) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
+        }
     };
 
     const int nk = (cl.Kgc + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile(0);
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > nk) kt_end = nk;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
         store_tile(0);
     }
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool has_next = kt + 1 < nk;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool has_next = kt + 1 < kt_end;
         if (has_next) load_tile(kt + 1);
         mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
         if (has_next) store_tile(cur ^ 1);
@@ -382,6 +603,10 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
         cur ^= 1;
     }
 
+    if (p.SH == 1 && p.SW == 1) {       // one class: output pixels are contiguous, shared epilogue (+ split-K)
+        store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split);
+        return;
+    }
     const int l32 = lane & 31, kh = lane >> 5;
     const int HW = p.H * p.W;
 #pragma unroll
@@ -409,6 +634,37 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
                 }
             }
         }
+    }
+}
+
+// out[(img*M + m)*PIX + pix] = act((sum_s partial[s][m][n]) * scale[m] + shift[m] + res), n = img*PIX + pix
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial,
+                                                                 float* __restrict__ out, int M, int Ng, int PIX,
+                                                                 FastDiv d_pix, int splits, Epilogue ep) {
+    const int64_t total = (int64_t)M * Ng;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Ng);
+        const int n = (int)(i - (int64_t)m * Ng);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += partial[(int64_t)s * total + i];
+        const int im = fdiv(n, d_pix);
+        const int pix = n - im * PIX;
+        const int64_t o = ((int64_t)im * M + m) * PIX + pix;
+        if (ep.scale) v *= ep.scale[m];
+        if (ep.shift) v += ep.shift[m];
+        if (ep.res) v += ep.res[o];
+        out[o] = rg_apply_act(v, ep.act, ep.slope);
+    }
+}
+
+// w[K][C][RS] -> wt[K][RS][C]
+__global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __restrict__ wt, int64_t total, int C, int RS) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int rs = (int)(t % RS);
+        const int64_t k = t / RS;
+        wt[i] = w[(k * C + c) * RS + rs];
     }
 }
 
@@ -539,6 +795,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     out[i] = s;
 }
 
+
+static bool fits_buffer(int64_t elems) { return elems > 0 && elems * 4 < (1ll << 31); }
+
 static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW,
                         int P, int Q) {
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K; p.KH = KH; p.KW = KW;
@@ -548,9 +807,15 @@ static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int
     p.d_pq = make_fastdiv(P * Q);
     p.d_q = make_fastdiv(Q);
     p.a_vec4 = 0;
-    p.ktiles_per_split = 0;
+    p.ktiles_per_split = 1 << 30;
     p.splits = 1;
+    p.partial = nullptr;
+    p.x_bytes = p.w_bytes = p.y_bytes = p.partial_bytes = 0;
+    p.d_c = make_fastdiv(C);
+    p.d_k = make_fastdiv(K);
 }
+
+
 
 static int validate(const char* op, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW,
                     int P, int Q) {
@@ -560,40 +825,101 @@ static int validate(const char* op, int N, int C, int H, int W, int K, int KH, i
     // every output pixel must start inside the padded input
     RG_REQUIRE((int64_t)(P - 1) * SH - PH < H && (int64_t)(Q - 1) * SW - PW < W, "%s: output larger than input allows", op);
     RG_REQUIRE((int64_t)N * P * Q < (1ll << 31) && (int64_t)C * KH * KW < (1ll << 31) && (int64_t)N * H * W < (1ll << 31) &&
-                   (int64_t)C * H * W < (1ll << 31) && (int64_t)K * P * Q < (1ll << 31),
+                   (int64_t)C * H * W < (1ll << 31) && (int64_t)K * P * Q < (1ll << 31) &&
+                   (int64_t)K * KH * KW < (1ll << 31),
                "%s: dimension product exceeds 2^31", op);
+    RG_REQUIRE(fits_buffer((int64_t)N * C * H * W) && fits_buffer((int64_t)N * K * P * Q) &&
+                   fits_buffer((int64_t)K * C * KH * KW),
+               "%s: every tensor must be smaller than 2 GiB (32-bit buffer offsets)", op);
     return RG_OK;
 }
-
-// tile selection: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 32x256
-static int pick_tile(int M, int64_t Ng) {
-    if (M <= 32) return 3;
-    const int64_t big = (int64_t)rg::cdiv(M, 128) * rg::cdiv64(Ng, 128);
-    if (M <= 64) return (int64_t)rg::cdiv64(Ng, 128) >= 256 ? 1 : 2;
-    if (big >= 384) return 0;
-    return 2;
-}
-
-}  // namespace
-
-#define RG_TILE_DISPATCH(tile, KERNEL, grid_expr, ...)                                   \
-    switch (tile) {                                                                      \
-        case 0: { constexpr int BM_ = 128, BN_ = 128; auto g = grid_expr;                \
-                  hipLaunchKernelGGL((KERNEL<128, 128, 2, 2>), g, dim3(NT), 0, stream, __VA_ARGS__); } break; \
-        case 1: { constexpr int BM_ = 64, BN_ = 128; auto g = grid_expr;                 \
-                  hipLaunchKernelGGL((KERNEL<64, 128, 2, 2>), g, dim3(NT), 0, stream, __VA_ARGS__); } break;  \
-        case 2: { constexpr int BM_ = 64, BN_ = 64; auto g = grid_expr;                  \
-                  hipLaunchKernelGGL((KERNEL<64, 64, 2, 2>), g, dim3(NT), 0, stream, __VA_ARGS__); } break;   \
-        default: { constexpr int BM_ = 32, BN_ = 256; auto g = grid_expr;                \
-                  hipLaunchKernelGGL((KERNEL<32, 256, 1, 4>), g, dim3(NT), 0, stream, __VA_ARGS__); } break;  \
-    }
 
 static const int kTileBM[4] = {128, 64, 64, 32};
 static const int kTileBN[4] = {128, 128, 64, 256};
 
-extern "C" int rg_conv2d_fwd(const float* x, const float* w, float* y, int N, int C, int H, int W, int K, int KH, int KW,
-                             int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
-                             const float* residual, int act, float slope, hipStream_t stream) {
+struct GemmPlan {
+    int tile, m_tiles, n_tiles, splits, ktiles_per_split;
+};
+
+// Development override: RG_CONV_FORCE="tile,splits" (tile 0..3 or -1, splits >= 1 or -1) pins the choice.
+static void force_override(int* tile, int* splits) {
+    static int f_tile = -2, f_splits = -2;
+    if (f_tile == -2) {
+        f_tile = -1;
+        f_splits = -1;
+        const char* e = getenv("RG_CONV_FORCE");
+        if (e) sscanf(e, "%d,%d", &f_tile, &f_splits);
+    }
+    if (f_tile >= 0 && f_tile <= 3) *tile = f_tile;
+    if (f_splits >= 1) *splits = f_splits;
+}
+
+// Tile + split-K choice for the fwd / dgrad GEMMs (M x Ng outputs, Kg reduction), allow_split = single-class output.
+static GemmPlan plan_gemm(int M, int64_t Ng, int64_t Kg, bool allow_split) {
+    GemmPlan pl;
+    if (M <= 32) pl.tile = 3;
+    else if (M <= 64) pl.tile = Ng >= 128 ? 1 : 2;
+    else pl.tile = Ng >= 128 ? 0 : 2;
+    auto tiles_of = [&](int t) { return (int64_t)rg::cdiv(M, kTileBM[t]) * rg::cdiv64(Ng, kTileBN[t]); };
+    const int64_t nk = rg::cdiv64(Kg, BK);
+    // a big tile that cannot be split deep enough to fill the chip: fall back to 64x64
+    if (pl.tile == 0 && tiles_of(0) < 256 && (!allow_split || nk < 16)) pl.tile = 2;
+    int splits = 1;
+    const int64_t tiles = tiles_of(pl.tile);
+    if (allow_split && tiles < 384 && nk >= 16) {
+        int64_t want = rg::cdiv64(512, tiles);
+        if (want > nk / 8) want = nk / 8;       // >= 8 k-tiles (128 reduction steps) per split
+        if (want > 16) want = 16;
+        while (want > 1 && (int64_t)want * M * Ng * 4 >= (1ll << 31)) --want;      // partial buffer < 2 GiB
+        if (want > 1) splits = (int)want;
+    }
+    force_override(&pl.tile, &splits);
+    if (!allow_split) splits = 1;
+    pl.m_tiles = rg::cdiv(M, kTileBM[pl.tile]);
+    pl.n_tiles = (int)rg::cdiv64(Ng, kTileBN[pl.tile]);
+    pl.ktiles_per_split = (int)rg::cdiv64(nk > 0 ? nk : 1, splits);
+    pl.splits = (int)rg::cdiv64(nk > 0 ? nk : 1, pl.ktiles_per_split);
+    return pl;
+}
+
+static unsigned finish_grid(int64_t n) {
+    int64_t g = rg::cdiv64(n, 256);
+    if (g > 4096) g = 4096;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+#define RG_FWD_LAUNCH(BM_, BN_, WM_, WN_)                                                                             \
+    if (bmode == 2) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 2, true>), grid, dim3(NT), 0, stream, p); \
+    else if (bmode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, true>), grid, dim3(NT), 0, stream, p); \
+    else if (avec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, true>), grid, dim3(NT), 0, stream, p);  \
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, false>), grid, dim3(NT), 0, stream, p)
+
+#define RG_DGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                          \
+    if (mode == 2) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(NT), 0, stream, dp);    \
+    else if (mode == 1) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(NT), 0, stream, dp); \
+    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(NT), 0, stream, dp)
+
+#define RG_TILE_SWITCH(tile, LAUNCH)      \
+    switch (tile) {                       \
+        case 0: LAUNCH(128, 128, 2, 2); break; \
+        case 1: LAUNCH(64, 128, 2, 2); break;  \
+        case 2: LAUNCH(64, 64, 2, 2); break;   \
+        default: LAUNCH(32, 256, 1, 4); break; \
+    }
+
+extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
+    const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
+    return pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
+}
+
+// w_krsc (optional): weights re-laid out as [K][KH*KW][C] (rg_weights_to_krsc); with C % 16 == 0 it selects the
+// (r,s)-major reduction order whose pixel gather tests the padding bounds once per 16-deep k-tile.
+extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y, int N, int C, int H, int W,
+                             int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
+                             const float* shift, const float* residual, int act, float slope, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_fwd", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(x && w && y, "rg_conv2d_fwd: null tensor");
     ConvP p;
@@ -601,18 +927,51 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, float* y, int N, in
     p.x = x; p.w = w; p.y = y;
     p.ep = Epilogue{scale, shift, residual, act, slope};
     p.M = K; p.Ng = N * P * Q; p.Kg = C * KH * KW;
-    p.a_vec4 = (p.Kg % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
-    const int tile = pick_tile(p.M, p.Ng);
-    p.m_tiles = rg::cdiv(p.M, kTileBM[tile]);
-    p.n_tiles = rg::cdiv(p.Ng, kTileBN[tile]);
+    p.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
+    p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
+    p.y_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
+    const bool is1x1 = KH == 1 && KW == 1;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+    const bool avec = (p.Kg % 4 == 0) && aligned;
+    int bmode = 0;
+    if (avec && is1x1 && SH == 1 && SW == 1 && PH == 0 && PW == 0 && ((H * W) % 4 == 0)) bmode = 2;
+    else if (avec && C % 16 == 0 && (is1x1 || (w_krsc && (reinterpret_cast<uintptr_t>(w_krsc) & 15) == 0))) {
+        bmode = 1;
+        if (!is1x1) p.w = w_krsc;
+    }
+    GemmPlan pl = plan_gemm(p.M, p.Ng, p.Kg, true);
+    const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace)) {     // no scratch given: run unsplit
+        pl.splits = 1;
+        pl.ktiles_per_split = 1 << 30;
+    }
+    p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
+    p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
+    p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    p.partial_bytes = (unsigned)need;
     rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
-    RG_TILE_DISPATCH(tile, conv_fwd_kernel, dim3(p.m_tiles * p.n_tiles), p);
+    const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
+    RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH);
+    if (pl.splits > 1) {
+        if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * p.Ng)), dim3(256), 0, stream,
+                           p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
+    }
     return rg::check_launch("rg_conv2d_fwd");
 }
 
-extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W, int K, int KH,
-                               int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
-                               const float* shift, const float* residual, int act, float slope, hipStream_t stream) {
+extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
+    if (SH != 1 || SW != 1) return 0;
+    const GemmPlan pl = plan_gemm(C, (int64_t)N * H * W, (int64_t)K * KH * KW, true);
+    return pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
+}
+
+// w_krsc: the weights re-laid out as [K][KH*KW][C] by rg_weights_to_krsc (may be NULL; for 1x1 filters the
+// original tensor already has that layout and is used directly).
+extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H,
+                               int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
+                               const float* scale, const float* shift, const float* residual, int act, float slope,
+                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_dgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(dy && w && dx, "rg_conv2d_dgrad: null tensor");
     RG_REQUIRE(SH <= 2 && SW <= 2, "rg_conv2d_dgrad: stride > 2 not supported (got %d,%d)", SH, SW);
@@ -622,7 +981,10 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
     p.x = dy; p.w = w; p.y = dx;
     p.ep = Epilogue{scale, shift, residual, act, slope};
     p.M = C;
-    int64_t ng_max = 0;
+    p.x_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
+    p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
+    p.y_bytes = (unsigned)((int64_t)N * C * H * W * 4);
+    int64_t ng_max = 0, kg_max = 0;
     double flops = 0.0;
     for (int ah = 0; ah < SH; ++ah)
         for (int aw = 0; aw < SW; ++aw) {
@@ -640,21 +1002,57 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, float* dx, int N
             cl.d_hw = make_fastdiv(cl.Hc * cl.Wc);
             cl.d_w = make_fastdiv(cl.Wc);
             if (cl.Ngc > ng_max) ng_max = cl.Ngc;
+            if (cl.Kgc > kg_max) kg_max = cl.Kgc;
             flops += 2.0 * C * (double)cl.Ngc * cl.Kgc;
         }
-    const int tile = pick_tile(p.M, ng_max * SH * SW);
-    p.m_tiles = rg::cdiv(p.M, kTileBM[tile]);
+    const bool one_class = SH == 1 && SW == 1;
+    // weight operand layout / loader
+    const bool is1x1 = KH == 1 && KW == 1;
+    const bool w_al = (reinterpret_cast<uintptr_t>(w) & 15) == 0, dy_al = (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    const float* wk = is1x1 ? (w_al ? w : nullptr)
+                            : ((w_krsc && (reinterpret_cast<uintptr_t>(w_krsc) & 15) == 0) ? w_krsc : nullptr);
+    int mode = 0;
+    if (wk && C % 4 == 0) {
+        if (is1x1 && one_class && PH == 0 && PW == 0 && ((P * Q) % 4 == 0) && dy_al) mode = 2;
+        else if (K % 16 == 0) mode = 1;
+        if (mode) p.w = wk;
+    }
+    GemmPlan pl = plan_gemm(p.M, one_class ? ng_max : ng_max * SH * SW, kg_max, one_class);
+    const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
+    if (need > workspace_bytes || (need && !workspace)) {
+        pl.splits = 1;
+        pl.ktiles_per_split = 1 << 30;
+    }
+    p.m_tiles = pl.m_tiles;
     int nt_max = 0;
     for (int i = 0; i < SH * SW; ++i) {
-        dp.cls[i].ntiles = rg::cdiv(dp.cls[i].Ngc, kTileBN[tile]);
+        dp.cls[i].ntiles = rg::cdiv(dp.cls[i].Ngc, kTileBN[pl.tile]);
         if (dp.cls[i].ntiles > nt_max) nt_max = dp.cls[i].ntiles;
     }
     p.n_tiles = nt_max;
     p.Ng = (int)ng_max;
     p.Kg = K * KH * KW;
+    p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
+    p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    p.partial_bytes = (unsigned)need;
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops);
-    RG_TILE_DISPATCH(tile, conv_dgrad_kernel, dim3(p.m_tiles * nt_max, 1, SH * SW), dp);
+    const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
+    RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
+    if (pl.splits > 1) {
+        if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * ng_max)), dim3(256), 0, stream,
+                           p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+    }
     return rg::check_launch("rg_conv2d_dgrad");
+}
+
+extern "C" int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, hipStream_t stream) {
+    RG_REQUIRE(w && w_krsc && K > 0 && C > 0 && KH > 0 && KW > 0, "rg_weights_to_krsc: bad arguments");
+    const int64_t total = (int64_t)K * C * KH * KW;
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(weights_to_krsc_kernel, dim3(finish_grid(total)), dim3(256), 0, stream, w, w_krsc, total, C,
+                       KH * KW);
+    return rg::check_launch("rg_weights_to_krsc");
 }
 
 namespace {
@@ -669,10 +1067,10 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     pl.n_tiles = rg::cdiv(Ng, kTileBN[pl.tile]);
     const int64_t nk = rg::cdiv64(Kg, BK);
     const int64_t mn = (int64_t)pl.m_tiles * pl.n_tiles;
-    int64_t want = rg::cdiv64(1024, mn);  // aim at ~4 workgroups per CU
-    if (want > nk / 4) want = nk / 4;     // keep >= 4 k-tiles per split
+    int64_t want = rg::cdiv64(768, mn);   // aim at ~3 workgroups per CU
+    if (want > nk / 16) want = nk / 16;   // >= 16 k-tiles per split: keeps the partial-tile traffic small
     if (want < 1) want = 1;
-    if (want > 2048) want = 2048;
+    if (want > 512) want = 512;
     pl.ktiles_per_split = (int)rg::cdiv64(nk, want);
     pl.splits = (int)rg::cdiv64(nk, pl.ktiles_per_split);
     return pl;
@@ -705,10 +1103,14 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         return RG_ERR_WORKSPACE;
     }
     p.y = pl.splits > 1 ? static_cast<float*>(workspace) : dw;
-    const int tile = pl.tile;
+    const dim3 grid(p.m_tiles * p.n_tiles, 1, pl.splits);
     {
         rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
-        RG_TILE_DISPATCH(tile, conv_wgrad_kernel, dim3(p.m_tiles * p.n_tiles, 1, pl.splits), p);
+        switch (pl.tile) {
+            case 0: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(NT), 0, stream, p); break;
+            case 2: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(NT), 0, stream, p); break;
+            default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4>), grid, dim3(NT), 0, stream, p); break;
+        }
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (pl.splits > 1) {
             const int64_t n = (int64_t)p.M * p.Ng;

@@ -162,6 +162,9 @@ class FDGANModel(object):
             self.schedulers.append(get_scheduler(optimizer, opt))
         # data-parallel gradient reduction (no-op unless torch.distributed is initialised)
         self.reducers = [GradReducer(o) for o in self.optimizers]
+        if self.reducers[0].active():
+            g_params = list(self.net_G.parameters())
+            self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_params)
 
     def set_input(self, input):
         input1, input2 = input
@@ -256,16 +259,23 @@ class FDGANModel(object):
         self.fake = self.fake.detach()
 
     def optimize_parameters(self):
+        """Reference order (:216-229): forward; D_id update; D_pd update; G(+E) update.  The D_pd backward does not
+        read D_id's weights, so D_id's optimizer step is issued after it: D_id's gradient all-reduce (RCCL, side
+        stream) then overlaps the D_pd backward; in the generator update G's gradients are reduced while the
+        encoder's backward still runs (`_rg_after_backward`).  Results are those of the reference order."""
         self.forward()
 
         self.optimizer_Di.zero_grad()
         self.backward_Di()
-        self.reducers[1].reduce()
-        self.optimizer_Di.step()
+        self.reducers[1].reduce_async()
 
         self.optimizer_Dp.zero_grad()
         self.backward_Dp()
-        self.reducers[2].reduce()
+        self.reducers[2].reduce_async()
+
+        self.reducers[1].wait()
+        self.optimizer_Di.step()
+        self.reducers[2].wait()
         self.optimizer_Dp.step()
 
         self.optimizer_G.zero_grad()

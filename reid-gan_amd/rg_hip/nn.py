@@ -22,7 +22,24 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
-class Conv2d(RGModule):
+WEIGHT_EPOCH = [0]      # bumped by rg_hip.optim after every step (its kernels bypass torch's version counters)
+
+
+class _KrscCache(object):
+    """[K][KH*KW][C] copy of a filter tensor for the (r,s)-major kernels, rebuilt only when the weights changed."""
+
+    def _krsc(self):
+        w = self.weight
+        if w.shape[2] * w.shape[3] == 1 or w.shape[1] % 4 != 0:
+            return None
+        key = (WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        if getattr(self, "_wk_key", None) != key:
+            self._wk = ops.weights_to_krsc(w.detach())
+            self._wk_key = key
+        return self._wk
+
+
+class Conv2d(RGModule, _KrscCache):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
         super(Conv2d, self).__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -43,7 +60,8 @@ class Conv2d(RGModule):
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
 
     def tf(self, tape, x, act=ACT_NONE, slope=0.0):
-        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, act=act, slope=slope)
+        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, act=act, slope=slope,
+                           w_krsc=self._krsc())
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
@@ -58,10 +76,11 @@ class Conv2d(RGModule):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
-        return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual)
+        return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual,
+                                w_krsc=self._krsc())
 
 
-class ConvTranspose2d(RGModule):
+class ConvTranspose2d(RGModule, _KrscCache):
     """weight [in][out][kh][kw] as torch; forward is the dgrad kernel, backward-data the forward kernel."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
@@ -95,7 +114,8 @@ class ConvTranspose2d(RGModule):
             y = ops.conv2d_dgrad(x, self.weight.view(K, C * KH * KW, 1, 1), (1, 1), 1, 0).view(x.shape[0], C, KH, KW)
             tape.push((x, None, act, slope))
             return y
-        y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, act=act, slope=slope)
+        y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, act=act, slope=slope,
+                             w_krsc=self._krsc())
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
@@ -110,7 +130,7 @@ class ConvTranspose2d(RGModule):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
-        return ops.conv2d_fwd(dy, self.weight, self.stride, self.padding, residual=residual)
+        return ops.conv2d_fwd(dy, self.weight, self.stride, self.padding, residual=residual, w_krsc=self._krsc())
 
 
 class Linear(RGModule):

@@ -70,7 +70,17 @@ def conv_out_size(H, W, KH, KW, stride, padding):
     return (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
 
 
-def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0):
+def weights_to_krsc(w):
+    """[K][C][KH][KW] -> [K][KH*KW][C] copy for the (r,s)-major kernels (1x1 filters need none)."""
+    w = _chk(w, "w")
+    K, C, KH, KW = w.shape
+    wt = torch.empty((K, KH * KW, C), dtype=torch.float32, device=w.device)
+    lib.rg_weights_to_krsc(_p(w), _p(wt), K, C, KH, KW, _stream())
+    return wt
+
+
+def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0,
+               w_krsc=None):
     x, w = _chk(x, "x"), _chk(w, "w")
     N, C, H, W = x.shape
     K, Cw, KH, KW = w.shape
@@ -83,12 +93,17 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
     scale, shift, residual = _chk(scale, "scale"), _chk(shift, "shift"), _chk(residual, "residual")
     if residual is not None and residual.shape != y.shape:
         raise ValueError("conv2d_fwd: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    lib.rg_conv2d_fwd(_p(x), _p(w), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
-                      _p(residual), act, slope, _stream())
+    if w_krsc is None and KH * KW > 1 and C % 16 == 0:
+        w_krsc = weights_to_krsc(w)
+    nbytes = lib.rg_conv2d_fwd_workspace(N, C, K, KH, KW, P, Q)
+    ws = workspace(nbytes, x.device) if nbytes else None
+    lib.rg_conv2d_fwd(_p(x), _p(w), _p(w_krsc), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
+                      _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
     return y
 
 
-def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0):
+def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0,
+                 w_krsc=None):
     """dx[N][C][H][W] from dy[N][K][P][Q] and w[K][C][KH][KW]; x_hw = (H, W) of the conv input.
     Also the forward of ConvTranspose2d (weight [in=K][out=C][KH][KW], output size x_hw)."""
     dy, w = _chk(dy, "dy"), _chk(w, "w")
@@ -103,8 +118,12 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
     scale, shift, residual = _chk(scale, "scale"), _chk(shift, "shift"), _chk(residual, "residual")
     if residual is not None and residual.shape != dx.shape:
         raise ValueError("conv2d_dgrad: residual shape mismatch")
-    lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
-                        _p(residual), act, slope, _stream())
+    if w_krsc is None and KH * KW > 1 and C % 4 == 0:
+        w_krsc = weights_to_krsc(w)
+    nbytes = lib.rg_conv2d_dgrad_workspace(N, C, H, W, K, KH, KW, sh, sw)
+    ws = workspace(nbytes, dy.device) if nbytes else None
+    lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(w_krsc), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale),
+                        _p(shift), _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
     return dx
 
 

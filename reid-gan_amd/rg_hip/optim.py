@@ -16,6 +16,7 @@ import torch
 from torch.optim import Optimizer
 
 from . import ops
+from .nn import WEIGHT_EPOCH
 
 _ALIGN = 64          # elements; keeps every view 256-byte aligned (float4 kernels, RCCL)
 
@@ -137,6 +138,7 @@ class Adam(_FlatOptimizer):
                           st + 1, self.grad_scale)
             for i in members:
                 self._steps[i] += 1
+        WEIGHT_EPOCH[0] += 1          # invalidates cached filter re-layouts
         return loss
 
 
@@ -164,4 +166,5 @@ class SGD(_FlatOptimizer):
             ops.sgd_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._buf[a0:a1], lr, mom, wd, not started, self.grad_scale)
             for i in members:
                 self._started[i] = True
+        WEIGHT_EPOCH[0] += 1
         return loss

@@ -96,6 +96,9 @@ class _NetFn(torch.autograd.Function):
             else:
                 grads.append(g)
         ctx.tape = None
+        hook = getattr(ctx.net, "_rg_after_backward", None)
+        if hook is not None and grads:      # e.g. start this network's gradient all-reduce while upstream runs
+            hook()
         return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + tuple(grads)
 
 

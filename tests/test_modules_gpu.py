@@ -7,7 +7,7 @@ at 1e-3 (measured: ~1e-5).  Gradients need a flip-robust metric: two fp32 implem
 such flip changes one row of a weight gradient by ~1/sqrt(#terms) (2e-2 in the max norm for the 256->512 PatchGAN
 layer, measured) although every kernel is exact — test_patch_discriminator_without_kinks shows all gradients agree
 to 1e-5 once the kink is removed (slope 1).  Gradients are therefore compared by relative L2 error per tensor
-(5e-3) and over all parameters (2e-3), with a loose max-norm guard against gross errors; quantities that are
+(1e-2) and over all parameters (2e-3), with a loose max-norm guard against gross errors; quantities that are
 noise-dominated even inside the reference (train-mode BatchNorm backward through 50 layers at tiny batch, where
 torch's fp32 CPU result is several % from its own fp64 result) are judged against an fp64 run of the oracle.
 """
@@ -72,7 +72,7 @@ def _check_grads_anchored(rg_mod, o32, o64, what, floor=2e-3, factor=3.0, tensor
     return l2_h, l2_c
 
 
-def _check_grads(rg_mod, o_mod, tol, what, skip=(), tol_tensor=5e-3, tol_max=0.5):
+def _check_grads(rg_mod, o_mod, tol, what, skip=(), tol_tensor=1e-2, tol_max=0.5):
     """relative L2 error over all parameters <= tol, per tensor <= tol_tensor, max norm <= tol_max."""
     og = dict(o_mod.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values() if p.grad is not None)

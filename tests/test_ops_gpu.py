@@ -45,6 +45,13 @@ CONV_CASES = [
     (5, 2048, 1, 1, 2, 1, 1, 1, 0),      # Linear 2048 -> 2 as 1x1
     (64, 512, 1, 1, 640, 1, 1, 1, 0),    # CM-style GEMM
     (3, 16, 17, 9, 24, 3, 3, 2, 1),      # odd spatial, stride 2
+    (8, 512, 8, 4, 512, 3, 3, 1, 1),     # layer4 3x3 on an 8x4 map: split-K, KRSC dgrad weights
+    (8, 2048, 8, 4, 512, 1, 1, 1, 0),    # layer4 1x1: float4 pixel loads + split-K
+    (8, 512, 8, 4, 2048, 1, 1, 1, 0),
+    (4, 512, 16, 8, 512, 4, 4, 2, 1),    # G en_conv5 (strided dgrad, 4 parity classes, KRSC weights)
+    (32, 512, 31, 15, 1, 4, 4, 1, 1),    # D_pd head at full batch: M = 1, deep split-K
+    (2, 256, 16, 8, 1024, 1, 1, 2, 0),   # downsample 1x1 stride 2 (empty parity classes in dgrad)
+    (2, 20, 12, 6, 36, 3, 3, 1, 1),      # C % 4 == 0 but tiny: KRSC path with ragged tiles
 ]
 
 
