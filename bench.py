@@ -70,11 +70,24 @@ def synth_inputs(b, dev, seed):
     return in1, in2
 
 
-def cpu_baseline(sample_pairs=2):
+def host_cores():
+    """CPU threads this process may really use: affinity mask, then the cgroup CPU quota (the GPU boxes expose
+    256 logical CPUs but grant a 16-CPU share; oversubscribing oneDNN's thread pool makes it crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("RG_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(sample_pairs=8):
     """The reference step on the host cores: oracle restatement (checked against the reference's modules by
     tests/golden) at a bounded sample so the default run stays within minutes."""
     from oracle import ref_torch as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     oE = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True), O.OEltwiseSubEmbed(True, True, 2048, 2))
@@ -88,7 +101,7 @@ def cpu_baseline(sample_pairs=2):
     step.step(*batch)                                       # warm-up (allocator, oneDNN primitive caches)
     log("cpu baseline warm-up step done")
     t0 = time.time()
-    n = 2
+    n = 3
     for _ in range(n):
         step.step(*batch)
         log("cpu baseline step done")
@@ -196,7 +209,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle step on %d host cores) ..." % (os.cpu_count() or 1))
+        log("cpu baseline (oracle step on %d host threads) ..." % host_cores())
         cpu = cpu_baseline()
         log("cpu baseline done: %.3f images/s" % cpu["value"])
 

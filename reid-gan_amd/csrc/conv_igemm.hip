@@ -126,9 +126,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <typename T>
+// One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called after k-steps 4..7: the kernels use it to write the
+// NEXT tile's staged registers into the other LDS buffer, a quarter at a time, so those ds_writes (and the vmcnt
+// wait in front of them) issue in the shadow of the 64-cycle MFMAs instead of after them.
+template <typename T, typename Hook>
 __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float (*Bs)[T::LDB],
-                                         floatx16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+                                         floatx16 (&acc)[T::TM][T::TN], int wm, int wn, int lane, Hook hook) {
     const int l32 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
@@ -143,8 +146,12 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
 #pragma unroll
             for (int j = 0; j < T::TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (ks >= BK / 4) hook(ks - BK / 4);
     }
 }
+
+// true when element e of a CNT-element staging array belongs to quarter q (q < 0: every quarter)
+__device__ __forceinline__ constexpr bool in_quarter(int e, int cnt, int q) { return q < 0 || (e * 4) / cnt == q; }
 
 
 // ---- raw buffer access: 32-bit byte offsets from a wave-uniform base, hardware range check (a load beyond
@@ -370,29 +377,32 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
             }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int q) {
+        constexpr int NA = ALoadK<BM, AVEC>::NA;
 #pragma unroll
-        for (int i = 0; i < ALoadK<BM, AVEC>::NA; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int v = tid + NT * i;
             if (AVEC) {
                 const int row = v >> 2, kq = (v & 3) * 4;
                 if (v < BM * 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) As[buf][kq + j][row] = ra[4 * i + j];
+                    for (int j = 0; j < 4; ++j)
+                        if (in_quarter(4 * i + j, 4 * NA, q)) As[buf][kq + j][row] = ra[4 * i + j];
                 }
             } else {
-                if (v < BM * BK) As[buf][v & 15][v >> 4] = ra[i];
+                if (v < BM * BK && in_quarter(i, NA, q)) As[buf][v & 15][v >> 4] = ra[i];
             }
         }
         if (BMODE == 2) {
 #pragma unroll
             for (int i = 0; i < BVCNT; ++i) {
                 const int kk = vrow0 + i * BVSTEP;
-                if (kk < BK) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
+                if (kk < BK && in_quarter(i, BVCNT, q)) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
+            for (int i = 0; i < T::BCNT; ++i)
+                if (in_quarter(i, T::BCNT, q)) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
         }
     };
 
@@ -402,15 +412,16 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
     if (kt_end > nk) kt_end = nk;
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
-        store_tile(0);
+        store_tile(0, -1);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool has_next = kt + 1 < kt_end;
         if (has_next) load_tile(kt + 1);
-        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
-        if (has_next) store_tile(cur ^ 1);
+        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int q) {
+            if (has_next) store_tile(cur ^ 1, q);
+        });
         __syncthreads();
         cur ^= 1;
     }
@@ -561,26 +572,28 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
             for (int i = 0; i < T::BCNT; ++i) rb[i] = bload(rdy, o0 + (unsigned)i * kstride);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int q) {
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < ACNT0; ++i) As[buf][ak0 + i * AKSTEP][acol] = ra[i];
+            for (int i = 0; i < ACNT0; ++i)
+                if (in_quarter(i, ACNT0, q)) As[buf][ak0 + i * AKSTEP][acol] = ra[i];
         } else {
 #pragma unroll
             for (int i = 0; i < AVCNT; ++i) {
                 const int kk = avrow0 + i * AVSTEP;
-                if (kk < BK) *reinterpret_cast<float4*>(&As[buf][kk][4 * avcol]) = rav[i];
+                if (kk < BK && in_quarter(i, AVCNT, q)) *reinterpret_cast<float4*>(&As[buf][kk][4 * avcol]) = rav[i];
             }
         }
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < BVCNT; ++i) {
                 const int kk = vrow0 + i * BVSTEP;
-                if (kk < BK) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
+                if (kk < BK && in_quarter(i, BVCNT, q)) *reinterpret_cast<float4*>(&Bs[buf][kk][4 * vcol]) = rbv[i];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < T::BCNT; ++i) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
+            for (int i = 0; i < T::BCNT; ++i)
+                if (in_quarter(i, T::BCNT, q)) Bs[buf][bk0 + i * BKSTEP][bcol] = rb[i];
         }
     };
 
@@ -590,15 +603,16 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
     if (kt_end > nk) kt_end = nk;
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
-        store_tile(0);
+        store_tile(0, -1);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool has_next = kt + 1 < kt_end;
         if (has_next) load_tile(kt + 1);
-        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
-        if (has_next) store_tile(cur ^ 1);
+        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int q) {
+            if (has_next) store_tile(cur ^ 1, q);
+        });
         __syncthreads();
         cur ^= 1;
     }
@@ -637,6 +651,70 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
     }
 }
 
+// Data gradient for layers with <= 4 input channels (the RGB stem, FD/reid/models/resnet.py via torchvision conv1;
+// the generator's 64 -> 3 output ConvTranspose, FD/fdgan/networks.py:133-138).  A 32-row MFMA tile would be > 87 %
+// padding there, so this is a direct VALU kernel: one thread per input pixel of one stride-parity class (uniform
+// tap set per block), all C channels in registers, the filter bank [K][KH*KW][4] staged once in LDS (broadcast
+// float4 reads), dy read coalesced along the row.
+template <int CMAX>
+__global__ __launch_bounds__(256) void conv_dgrad_smallc_kernel(const DgradP dp) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [K][RS][CMAX]
+    const ConvP& p = dp.c;
+    const int ci = blockIdx.z;
+    const DgradClass& cl = dp.cls[ci];
+    const int ah = ci / p.SW, aw = ci % p.SW;
+    const int RS = p.KH * p.KW, PQ = p.P * p.Q, HW = p.H * p.W;
+    for (int i = threadIdx.x; i < p.K * RS * CMAX; i += blockDim.x) {
+        const int c = i % CMAX, t = i / CMAX;          // t = ko*RS + rs
+        const int ko = t / RS, rs = t - ko * RS;
+        wl[i] = c < p.C ? p.w[((int64_t)ko * p.C + c) * RS + rs] : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= cl.Ngc) return;
+    const int img = fdiv(n, cl.d_hw);
+    const int rem = n - img * cl.Hc * cl.Wc;
+    const int hc = fdiv(rem, cl.d_w);
+    const int wc = rem - hc * cl.Wc;
+    const int h = ah + p.SH * hc, w = aw + p.SW * wc;
+    const int hb = (h + p.PH - cl.r0) / p.SH, wb = (w + p.PW - cl.s0) / p.SW;
+    const float* dyb = p.x + (int64_t)img * p.K * PQ;
+    float acc[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+    for (int j = 0; j < cl.nrh; ++j) {
+        const int pp = hb - j;
+        if ((unsigned)pp >= (unsigned)p.P) continue;
+        for (int jj = 0; jj < cl.nrw; ++jj) {
+            const int qq = wb - jj;
+            if ((unsigned)qq >= (unsigned)p.Q) continue;
+            const int rs = (cl.r0 + p.SH * j) * p.KW + cl.s0 + p.SW * jj;
+            const float* src = dyb + pp * p.Q + qq;
+            const float* wrow = wl + rs * CMAX;
+#pragma unroll 4
+            for (int ko = 0; ko < p.K; ++ko) {
+                const float v = src[(int64_t)ko * PQ];
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + (int64_t)ko * RS * CMAX);
+                acc[0] += v * wv.x;
+                if (CMAX > 1) acc[1] += v * wv.y;
+                if (CMAX > 2) acc[2] += v * wv.z;
+                if (CMAX > 3) acc[3] += v * wv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < p.C) {
+            float v = acc[c];
+            if (p.ep.scale) v *= p.ep.scale[c];
+            if (p.ep.shift) v += p.ep.shift[c];
+            const int64_t o = ((int64_t)img * p.C + c) * HW + h * p.W + w;
+            if (p.ep.res) v += p.ep.res[o];
+            p.y[o] = rg_apply_act(v, p.ep.act, p.ep.slope);
+        }
+    }
+}
+
 // out[(img*M + m)*PIX + pix] = act((sum_s partial[s][m][n]) * scale[m] + shift[m] + res), n = img*PIX + pix
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial,
                                                                  float* __restrict__ out, int M, int Ng, int PIX,
@@ -669,7 +747,12 @@ __global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradient: reduction over N*P*Q split across blockIdx.z, partials to a workspace
+// weight gradient: dw[K][C*KH*KW] = dy[K][N*P*Q] x im2col(x)^T; the reduction (output pixels) is split across
+// blockIdx.z, partial tiles go to a workspace and a second kernel sums them.  Lanes run along the reduction axis
+// (16 consecutive output pixels: coalesced rows of dy and x); each thread owns fixed GEMM rows / columns.
+// Column order: (c, r, s) as in the checkpoint layout, or — p.a_vec4 != 0, C % 16 == 0 — (r, s)-major n' = rs*C + c,
+// which lets a whole 16..128-column tile share one filter tap (one padding test per k-tile instead of one per
+// element); the finishing kernel then writes dw back in [K][C][KH][KW] order.
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
@@ -682,19 +765,37 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
     const int mt = blockIdx.x % p.m_tiles, nt = blockIdx.x / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int split = blockIdx.z;
+    const rsrc_t rdy = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
 
     const int kk = tid & 15, r0 = tid >> 4;  // lanes run along the reduction (pixel) axis
     constexpr int ACNT = BM / 16, BCNT = BN / 16;
     const int PQ = p.P * p.Q, HW = p.H * p.W, RS = p.KH * p.KW;
+    const bool rsc = p.a_vec4 != 0;
+    // no padding and every window inside the image: no bounds test at all (all 1x1 layers)
+    const bool nopad = p.PH == 0 && p.PW == 0 && (p.P - 1) * p.SH + p.KH <= p.H && (p.Q - 1) * p.SW + p.KW <= p.W;
+    // (r,s)-major and the whole column tile inside one tap: one bounds test per lane per k-tile
+    const bool same_rs = rsc && (fdiv(n0, p.d_c) == fdiv(min(n0 + BN, p.Ng) - 1, p.d_c));
 
-    // B columns (c, r, s) handled by this thread are fixed for the whole reduction
-    int coff[BCNT], crs[BCNT];
+    // per-thread GEMM rows (dy channels) and columns (c, r, s): fixed for the whole reduction
+    unsigned aoff[ACNT];          // byte offset of row m inside one image of dy, or OOB
+#pragma unroll
+    for (int i = 0; i < ACNT; ++i) {
+        const int m = m0 + r0 + 16 * i;
+        aoff[i] = m < p.M ? (unsigned)m * (unsigned)PQ * 4u : OOB;
+    }
+    int coff[BCNT], crs[BCNT];    // element offset c*HW + r*W + s, packed (r,s) or -1
 #pragma unroll
     for (int i = 0; i < BCNT; ++i) {
         const int n = n0 + r0 + 16 * i;
         if (n < p.Ng) {
-            const int c = fdiv(n, p.d_rs);
-            const int rs = n - c * RS;
+            int c, rs;
+            if (rsc) {
+                rs = fdiv(n, p.d_c);
+                c = n - rs * p.C;
+            } else {
+                c = fdiv(n, p.d_rs);
+                rs = n - c * RS;
+            }
             const int r = fdiv(rs, p.d_kw);
             const int s = rs - r * p.KW;
             coff[i] = c * HW + r * p.W + s;
@@ -707,12 +808,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
 
     float ra[ACNT], rb[BCNT];
     floatx16 acc[T::TM][T::TN];
-#pragma unroll
-    for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    zero_acc<T>(acc);
 
     auto load_tile = [&](int kt) {
         const int g = kt * BK + kk;  // global output-pixel index n*P*Q + p*Q + q
@@ -726,27 +822,37 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
             h0 = pp * p.SH - p.PH;
             w0 = qq * p.SW - p.PW;
         }
-        const float* dyb = p.w + (int64_t)img * p.K * PQ + pq;
+        const unsigned abase = gvalid ? (unsigned)(img * p.K * PQ + pq) * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i) {
-            const int m = m0 + r0 + 16 * i;
-            ra[i] = (gvalid && m < p.M) ? dyb[(int64_t)m * PQ] : 0.f;
-        }
-        const float* xb = p.x + (int64_t)img * p.C * HW;
-        const int pix_off = h0 * p.W + w0;
+        for (int i = 0; i < ACNT; ++i) ra[i] = bload(rdy, (abase | aoff[i]) & OOB ? OOB : abase + aoff[i]);
+        const int xb = img * p.C * HW + h0 * p.W + w0;      // element index of (img, 0, h0, w0); may sit in the padding
+        if (nopad) {
 #pragma unroll
-        for (int i = 0; i < BCNT; ++i) {
-            const int r = crs[i] >> 16, s = crs[i] & 0xffff;
+            for (int i = 0; i < BCNT; ++i)
+                rb[i] = bload(rx, (gvalid && crs[i] >= 0) ? (unsigned)(xb + coff[i]) * 4u : OOB);
+        } else if (same_rs) {
+            const int r = crs[0] >> 16, s = crs[0] & 0xffff;
             const int h = h0 + r, w = w0 + s;
-            const bool ok = gvalid && crs[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            rb[i] = ok ? xb[coff[i] + pix_off] : 0.f;
+            const bool ok = gvalid && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+#pragma unroll
+            for (int i = 0; i < BCNT; ++i) rb[i] = bload(rx, (ok && crs[i] >= 0) ? (unsigned)(xb + coff[i]) * 4u : OOB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BCNT; ++i) {
+                const int r = crs[i] >> 16, s = crs[i] & 0xffff;
+                const int h = h0 + r, w = w0 + s;
+                const bool ok = gvalid && crs[i] >= 0 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                rb[i] = bload(rx, ok ? (unsigned)(xb + coff[i]) * 4u : OOB);
+            }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int q) {
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i) As[buf][kk][r0 + 16 * i] = ra[i];
+        for (int i = 0; i < ACNT; ++i)
+            if (in_quarter(i, ACNT, q)) As[buf][kk][r0 + 16 * i] = ra[i];
 #pragma unroll
-        for (int i = 0; i < BCNT; ++i) Bs[buf][kk][r0 + 16 * i] = rb[i];
+        for (int i = 0; i < BCNT; ++i)
+            if (in_quarter(i, BCNT, q)) Bs[buf][kk][r0 + 16 * i] = rb[i];
     };
 
     const int nk_total = (p.Kg + BK - 1) / BK;
@@ -756,45 +862,57 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
 
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
-        store_tile(0);
+        store_tile(0, -1);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool has_next = kt + 1 < kt_end;
         if (has_next) load_tile(kt + 1);
-        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane);
-        if (has_next) store_tile(cur ^ 1);
+        mma_tile<T>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int q) {
+            if (has_next) store_tile(cur ^ 1, q);
+        });
         __syncthreads();
         cur ^= 1;
     }
 
+    // partial (or final) tile: [split][M][Ng], columns contiguous
     const int l32 = lane & 31, kh = lane >> 5;
-    float* out = p.y + (int64_t)split * p.M * p.Ng;
+    const rsrc_t ro = make_rsrc(p.y, p.y_bytes);
+    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+    const unsigned rstride = (unsigned)p.Ng * 4u;
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int nn = n0 + wn * T::WTN + j * 32 + l32;
-        if (nn >= p.Ng) continue;
+        const unsigned ob = nn < p.Ng ? (unsigned)((((int64_t)split * p.M + mrow0) * p.Ng + nn) * 4) : OOB;
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) {
+        for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < p.M) out[(int64_t)m * p.Ng + nn] = acc[i][j][r];
+                const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
+                bstore(ro, (mrow0 + mo < p.M) ? ob + (unsigned)mo * rstride : OOB, acc[i][j][r]);
             }
-        }
     }
 }
 
-// dw[i] = sum_s ws[s][i]  (deterministic split-K combine; float4 when possible)
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits) {
+// dw[i] = sum_s ws[s][i]; with rsc != 0 the partial columns are (r,s)-major (n' = rs*C + c) and are written back in
+// the checkpoint order [K][C][RS].  Deterministic (fixed summation order).
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits,
+                                     int rsc, int C, int RS) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
-    out[i] = s;
+    if (!rsc) {
+        out[i] = s;
+        return;
+    }
+    const int64_t crs = (int64_t)C * RS;
+    const int64_t m = i / crs;
+    const int np = (int)(i - m * crs);
+    const int rs = np / C, c = np - rs * C;
+    out[m * crs + (int64_t)c * RS + rs] = s;
 }
-
 
 static bool fits_buffer(int64_t elems) { return elems > 0 && elems * 4 < (1ll << 31); }
 
@@ -1006,6 +1124,17 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
             flops += 2.0 * C * (double)cl.Ngc * cl.Kgc;
         }
     const bool one_class = SH == 1 && SW == 1;
+    if (C <= 4 && (size_t)K * KH * KW * 4 * sizeof(float) <= 64 * 1024) {      // RGB-sized outputs: direct kernel
+        int nmax = 0;
+        for (int i = 0; i < SH * SW; ++i)
+            if (dp.cls[i].Ngc > nmax) nmax = dp.cls[i].Ngc;
+        p.Ng = nmax;
+        p.Kg = K * KH * KW;
+        rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops);
+        hipLaunchKernelGGL((conv_dgrad_smallc_kernel<4>), dim3(rg::cdiv(nmax, 256), 1, SH * SW), dim3(256),
+                           (size_t)K * KH * KW * 4 * sizeof(float), stream, dp);
+        return rg::check_launch("rg_conv2d_dgrad(small-C)");
+    }
     // weight operand layout / loader
     const bool is1x1 = KH == 1 && KW == 1;
     const bool w_al = (reinterpret_cast<uintptr_t>(w) & 15) == 0, dy_al = (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
@@ -1071,6 +1200,7 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     if (want > nk / 16) want = nk / 16;   // >= 16 k-tiles per split: keeps the partial-tile traffic small
     if (want < 1) want = 1;
     if (want > 512) want = 512;
+    while (want > 1 && want * (int64_t)M * Ng * 4 >= (1ll << 31)) --want;
     pl.ktiles_per_split = (int)rg::cdiv64(nk, want);
     pl.splits = (int)rg::cdiv64(nk, pl.ktiles_per_split);
     return pl;
@@ -1079,7 +1209,6 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
 
 extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
     const WgradPlan pl = plan_wgrad(K, C * KH * KW, (int64_t)N * P * Q);
-    if (pl.splits <= 1) return 0;
     return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
 }
 
@@ -1097,12 +1226,21 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
     p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
-    const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
-    if (need > workspace_bytes || (need && !workspace)) {
+    const size_t need = (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float);      // see rg_conv2d_wgrad_workspace
+    if (need > workspace_bytes || !workspace) {
         rg::set_error("rg_conv2d_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
         return RG_ERR_WORKSPACE;
     }
-    p.y = pl.splits > 1 ? static_cast<float*>(workspace) : dw;
+    RG_REQUIRE(need < (1ull << 31), "rg_conv2d_wgrad: partial buffer exceeds 2 GiB");
+    // (r,s)-major columns: always through the workspace (the finishing kernel restores the checkpoint order)
+    static const int rsc_env = getenv("RG_WGRAD_RSC") ? atoi(getenv("RG_WGRAD_RSC")) : 0;
+    const bool rsc = rsc_env && (KH * KW > 1) && (C % 16 == 0);
+    const bool via_ws = pl.splits > 1 || rsc;
+    p.a_vec4 = rsc ? 1 : 0;
+    p.y = via_ws ? static_cast<float*>(workspace) : dw;
+    p.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
+    p.w_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
+    p.y_bytes = via_ws ? (unsigned)need : (unsigned)((int64_t)K * C * KH * KW * 4);
     const dim3 grid(p.m_tiles * p.n_tiles, 1, pl.splits);
     {
         rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
@@ -1112,10 +1250,10 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
             default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4>), grid, dim3(NT), 0, stream, p); break;
         }
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
-        if (pl.splits > 1) {
+        if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 256)), dim3(256), 0, stream,
-                               static_cast<const float*>(workspace), dw, n, pl.splits);
+                               static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
         }
     }
     return rg::check_launch("rg_conv2d_wgrad(reduce)");

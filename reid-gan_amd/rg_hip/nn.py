@@ -32,7 +32,8 @@ class _KrscCache(object):
         w = self.weight
         if w.shape[2] * w.shape[3] == 1 or w.shape[1] % 4 != 0:
             return None
-        key = (WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        arena = getattr(w, "_rg_arena", None)          # the fused optimizers bump their own arena's epoch
+        key = (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
         if getattr(self, "_wk_key", None) != key:
             self._wk = ops.weights_to_krsc(w.detach())
             self._wk_key = key

@@ -38,6 +38,7 @@ class Arena(object):
             self.offsets.append(off)
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.size = off
+        self.epoch = 0           # bumped by every optimizer step: invalidates cached filter re-layouts
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         for p, o in zip(params, self.offsets):
@@ -138,7 +139,7 @@ class Adam(_FlatOptimizer):
                           st + 1, self.grad_scale)
             for i in members:
                 self._steps[i] += 1
-        WEIGHT_EPOCH[0] += 1          # invalidates cached filter re-layouts
+        a.epoch += 1                  # invalidates cached filter re-layouts of THIS arena's layers
         return loss
 
 
@@ -166,5 +167,5 @@ class SGD(_FlatOptimizer):
             ops.sgd_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._buf[a0:a1], lr, mom, wd, not started, self.grad_scale)
             for i in members:
                 self._started[i] = True
-        WEIGHT_EPOCH[0] += 1
+        a.epoch += 1
         return loss
