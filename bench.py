@@ -127,10 +127,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RG_FORCE_REDUCE") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         raise SystemExit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -152,7 +155,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +172,7 @@ def main():
         one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -204,7 +207,7 @@ def main():
                 "by_family": {k: {"ms_per_step": round(v["ms"] / args.profile_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) if v["flops"] else None,
                                   "launches": v["calls"] // args.profile_steps} for k, v in fam.items() if v["calls"]}}
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     cpu = None
@@ -231,7 +234,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -973,30 +973,52 @@ static void force_override(int* tile, int* splits) {
 }
 
 // Tile + split-K choice for the fwd / dgrad GEMMs (M x Ng outputs, Kg reduction), allow_split = single-class output.
+// A small cost model instead of thresholds: 256 CUs, up to 4 co-resident workgroups per CU sharing each SIMD's
+// matrix pipe.  Measured pipe utilisation vs co-residency (PMC, round 1): ~0.55 alone, ~0.7 with two, ~0.85 with
+// three or more.  Work that does not divide into 256-wide rounds leaves CUs idle (wave quantisation), so the split
+// count is chosen to land on full rounds; split-K pays for its partial tiles (write + read in the finishing kernel).
 static GemmPlan plan_gemm(int M, int64_t Ng, int64_t Kg, bool allow_split) {
+    const int64_t nk = rg::cdiv64(Kg > 0 ? Kg : 1, BK);
+    int cand[2], ncand = 0;
+    if (M <= 32) cand[ncand++] = 3;
+    else if (M <= 64) { if (Ng >= 128) cand[ncand++] = 1; cand[ncand++] = 2; }
+    else { if (Ng >= 128) cand[ncand++] = 0; cand[ncand++] = 2; }
+    // utilisation of a SIMD's matrix pipe with r co-resident workgroups per CU, relative efficiency of each tile
+    // shape (loads + LDS traffic per MFMA), fixed per-workgroup cost (first-tile latency, epilogue) in cycles
+    static const double util[5] = {1.0, 0.60, 0.85, 0.90, 0.92};
+    static const double tile_eff[4] = {1.0, 0.92, 0.85, 0.85};
+    const double fixed = 6000.0;
+    double best = 1e300;
     GemmPlan pl;
-    if (M <= 32) pl.tile = 3;
-    else if (M <= 64) pl.tile = Ng >= 128 ? 1 : 2;
-    else pl.tile = Ng >= 128 ? 0 : 2;
-    auto tiles_of = [&](int t) { return (int64_t)rg::cdiv(M, kTileBM[t]) * rg::cdiv64(Ng, kTileBN[t]); };
-    const int64_t nk = rg::cdiv64(Kg, BK);
-    // a big tile that cannot be split deep enough to fill the chip: fall back to 64x64
-    if (pl.tile == 0 && tiles_of(0) < 256 && (!allow_split || nk < 16)) pl.tile = 2;
-    int splits = 1;
-    const int64_t tiles = tiles_of(pl.tile);
-    if (allow_split && tiles < 384 && nk >= 16) {
-        int64_t want = rg::cdiv64(512, tiles);
-        if (want > nk / 8) want = nk / 8;       // >= 8 k-tiles (128 reduction steps) per split
-        if (want > 16) want = 16;
-        while (want > 1 && (int64_t)want * M * Ng * 4 >= (1ll << 31)) --want;      // partial buffer < 2 GiB
-        if (want > 1) splits = (int)want;
+    pl.tile = cand[0];
+    int best_s = 1;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int t = cand[ci];
+        const int64_t tiles = (int64_t)rg::cdiv(M, kTileBM[t]) * rg::cdiv64(Ng, kTileBN[t]);
+        const double mfma_per_ktile = (kTileBM[t] / 64.0) * (kTileBN[t] / 64.0) * 8.0 * 64.0 / tile_eff[t];
+        const int smax = allow_split ? 16 : 1;
+        for (int s = 1; s <= smax; ++s) {
+            if (s > 1 && (nk / s < 8 || (int64_t)s * M * Ng * 4 >= (1ll << 31))) break;
+            const int64_t kt = rg::cdiv64(nk, s);
+            const int64_t B = tiles * rg::cdiv64(nk, kt);
+            const double bt = kt * mfma_per_ktile + fixed;
+            const int64_t r = rg::cdiv64(B, 256);
+            double time = r <= 4 ? r * bt / util[r] : (double)B / 256.0 * bt / util[4];
+            if (s > 1) time += 2400.0 + (double)(s + 1) * M * (double)Ng * 4.0 / 3.0e12 * 2.0e9;   // finishing kernel
+            if (time < best * 0.97) {        // prefer bigger tiles / fewer splits unless clearly better
+                best = time;
+                pl.tile = t;
+                best_s = s;
+            }
+        }
     }
+    int splits = best_s;
     force_override(&pl.tile, &splits);
     if (!allow_split) splits = 1;
     pl.m_tiles = rg::cdiv(M, kTileBM[pl.tile]);
     pl.n_tiles = (int)rg::cdiv64(Ng, kTileBN[pl.tile]);
-    pl.ktiles_per_split = (int)rg::cdiv64(nk > 0 ? nk : 1, splits);
-    pl.splits = (int)rg::cdiv64(nk > 0 ? nk : 1, pl.ktiles_per_split);
+    pl.ktiles_per_split = (int)rg::cdiv64(nk, splits);
+    pl.splits = (int)rg::cdiv64(nk, pl.ktiles_per_split);
     return pl;
 }
 

@@ -13,6 +13,8 @@ reference's scripts and checkpoints rely on (FD/train.py:57, FD/fdgan/networks.p
 """
 from __future__ import absolute_import
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -41,11 +43,13 @@ class GradReducer(object):
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self._pending = []
         self._done = []          # element ranges already launched in this round
-        if self.arena is not None and world_size() > 1:
+        if self.active():
             optimizer.grad_scale = 1.0 / world_size()
 
     def active(self):
-        return self.arena is not None and world_size() > 1
+        # RG_FORCE_REDUCE=1 exercises the collective path on a single rank (RCCL init, side stream, waits)
+        forced = os.environ.get("RG_FORCE_REDUCE") == "1" and dist.is_available() and dist.is_initialized()
+        return self.arena is not None and (world_size() > 1 or forced)
 
     def _ranges_for(self, params):
         a = self.arena
