@@ -754,7 +754,9 @@ __global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __res
 // which lets a whole 16..128-column tile share one filter tap (one padding test per k-tile instead of one per
 // element); the finishing kernel then writes dw back in [K][C][KH][KW] order.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+// VEC: 1x1 / stride 1 / pad 0 with P*Q % 4 == 0 — both operands are [rows][pixels] with the reduction axis
+// contiguous, so each lane loads 4 consecutive pixels of one row (float4) instead of 4 scalar loads.
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
     __shared__ float As[2][BK][T::LDA];
@@ -806,11 +808,45 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
         }
     }
 
-    float ra[ACNT], rb[BCNT];
+    float ra[ACNT < 4 ? 4 : ACNT], rb[BCNT < 4 ? 4 : BCNT];
     floatx16 acc[T::TM][T::TN];
     zero_acc<T>(acc);
 
+    // VEC: thread v owns row (v >> 2) + 64*i and the pixel quad (v & 3)*4 of every k-tile
+    constexpr int AVN = (BM * 4 + NT - 1) / NT, BVN = (BN * 4 + NT - 1) / NT;
+    const int vrow = tid >> 2, vkq = (tid & 3) * 4;
+    unsigned avoff[AVN], bvoff[BVN];
+#pragma unroll
+    for (int i = 0; i < AVN; ++i) {
+        const int m = m0 + vrow + 64 * i;
+        avoff[i] = (vrow + 64 * i < BM && m < p.M) ? (unsigned)m * (unsigned)PQ * 4u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < BVN; ++i) {
+        const int c = n0 + vrow + 64 * i;
+        bvoff[i] = (vrow + 64 * i < BN && c < p.Ng) ? (unsigned)c * (unsigned)HW * 4u : OOB;
+    }
+
     auto load_tile = [&](int kt) {
+        if (VEC) {
+            const int g = kt * BK + vkq;
+            const bool gvalid = g < p.Kg;
+            const int img = gvalid ? fdiv(g, p.d_pq) : 0;
+            const int pq = g - img * PQ;
+            const unsigned ab = gvalid ? (unsigned)(img * p.K * PQ + pq) * 4u : OOB;
+            const unsigned bb = gvalid ? (unsigned)(img * p.C * HW + pq) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < AVN; ++i) {
+                const float4 t = bload4(rdy, ((ab | avoff[i]) & OOB) ? OOB : ab + avoff[i]);
+                ra[4 * i + 0] = t.x; ra[4 * i + 1] = t.y; ra[4 * i + 2] = t.z; ra[4 * i + 3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < BVN; ++i) {
+                const float4 t = bload4(rx, ((bb | bvoff[i]) & OOB) ? OOB : bb + bvoff[i]);
+                rb[4 * i + 0] = t.x; rb[4 * i + 1] = t.y; rb[4 * i + 2] = t.z; rb[4 * i + 3] = t.w;
+            }
+            return;
+        }
         const int g = kt * BK + kk;  // global output-pixel index n*P*Q + p*Q + q
         const bool gvalid = g < p.Kg;
         int img = 0, h0 = 0, w0 = 0, pq = 0;
@@ -847,6 +883,19 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
         }
     };
     auto store_tile = [&](int buf, int q) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < AVN; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (vrow + 64 * i < BM && in_quarter(4 * i + j, 4 * AVN, q)) As[buf][vkq + j][vrow + 64 * i] = ra[4 * i + j];
+#pragma unroll
+            for (int i = 0; i < BVN; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (vrow + 64 * i < BN && in_quarter(4 * i + j, 4 * BVN, q)) Bs[buf][vkq + j][vrow + 64 * i] = rb[4 * i + j];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ACNT; ++i)
             if (in_quarter(i, ACNT, q)) As[buf][kk][r0 + 16 * i] = ra[i];
@@ -1218,8 +1267,8 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     pl.n_tiles = rg::cdiv(Ng, kTileBN[pl.tile]);
     const int64_t nk = rg::cdiv64(Kg, BK);
     const int64_t mn = (int64_t)pl.m_tiles * pl.n_tiles;
-    int64_t want = rg::cdiv64(768, mn);   // aim at ~3 workgroups per CU
-    if (want > nk / 16) want = nk / 16;   // >= 16 k-tiles per split: keeps the partial-tile traffic small
+    int64_t want = rg::cdiv64(768, mn);   // three full rounds of 256 workgroups (measured best; the fwd cost model
+    if (want > nk / 16) want = nk / 16;   // over-splits here).  >= 16 k-tiles per split keeps partial traffic small
     if (want < 1) want = 1;
     if (want > 512) want = 512;
     while (want > 1 && want * (int64_t)M * Ng * 4 >= (1ll << 31)) --want;
@@ -1266,10 +1315,21 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     const dim3 grid(p.m_tiles * p.n_tiles, 1, pl.splits);
     {
         rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
+        const bool vec = KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0 && ((P * Q) % 4 == 0) &&
+                         (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
         switch (pl.tile) {
-            case 0: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(NT), 0, stream, p); break;
-            case 2: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(NT), 0, stream, p); break;
-            default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4>), grid, dim3(NT), 0, stream, p); break;
+            case 0:
+                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(NT), 0, stream, p);
+                break;
+            case 2:
+                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(NT), 0, stream, p);
+                break;
+            default:
+                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4, true>), grid, dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4, false>), grid, dim3(NT), 0, stream, p);
+                break;
         }
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {
