@@ -206,6 +206,7 @@ def main():
                 "measured_over": "%d profiled steps after the timed region" % args.profile_steps,
                 "by_family": {k: {"ms_per_step": round(v["ms"] / args.profile_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) if v["flops"] else None,
+                                  "gbps_algorithmic": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) if v["bytes"] else None,
                                   "launches": v["calls"] // args.profile_steps} for k, v in fam.items() if v["calls"]}}
     if use_dist:
         dist.barrier()

@@ -97,6 +97,12 @@ int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_act, const f
                     const float* gamma, const float* sum_dy, const float* sum_dy_xhat, float* dx, float* dres, int N,
                     int C, int HW, int train, int stat_is_var, float eps, int act, float slope, rg_stream_t stream);
 
+/* eval-mode backward in ONE pass (dx, dres and — when sum_dy / sum_dy_xhat are given — the affine-gradient sums) */
+int rg_bn_eval_bwd(const float* x, const float* dy, const float* y_act, const float* running_mean,
+                   const float* running_var, const float* gamma, float* dx, float* dres, float* sum_dy,
+                   float* sum_dy_xhat, int N, int C, int HW, float eps, int act, float slope, void* workspace,
+                   size_t workspace_bytes, rg_stream_t stream);
+
 /* ---- element-wise --------------------------------------------------------------------------- */
 int rg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, rg_stream_t stream);
 int rg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, rg_stream_t stream);

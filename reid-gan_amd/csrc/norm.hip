@@ -245,6 +245,75 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial_kernel(const float*
     }
 }
 
+// Eval-mode backward in ONE pass (running statistics: dx does not depend on the channel sums):
+//   g = dy * act'(y);  dx = gamma*invstd * g;  dres = g;  partial sums of g and g*xhat for dbeta / dgamma.
+// Same (slice, channel) decomposition as the reduction kernel, so it reads x, dy, y once (12 B/element) and
+// writes dx (+ dres) instead of the two-kernel reduce + apply sequence (28 B/element).
+__global__ __launch_bounds__(256) void bn_eval_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ yact,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ var,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                float* __restrict__ dres, float* __restrict__ part,
+                                                                int N, int C, int HW, int L, float eps, int act,
+                                                                float slope, int want_sums) {
+    const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const int64_t total = (int64_t)N * HW;
+    const int64_t beg = (int64_t)s * L;
+    int64_t end = beg + L;
+    if (end > total) end = total;
+    const float mu = mean[c];
+    const float is = rsqrtf(var[c] + eps);
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+        for (int64_t e = beg + (int64_t)threadIdx.x * 4; e < end; e += 256 * 4) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (act != RG_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(yact + o);
+                g.x *= act_grad_from_out(yv.x, act, slope);
+                g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope);
+                g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+            if (dx) *reinterpret_cast<float4*>(dx + o) = make_float4(gs * g.x, gs * g.y, gs * g.z, gs * g.w);
+            if (want_sums) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + o);
+                s1 += (g.x + g.y) + (g.z + g.w);
+                s2 += (g.x * (xv.x - mu) + g.y * (xv.y - mu)) + (g.z * (xv.z - mu) + g.w * (xv.w - mu));
+            }
+        }
+    } else {
+        for (int64_t e = beg + threadIdx.x; e < end; e += 256) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            float g = dy[o];
+            if (act != RG_ACT_NONE) g *= act_grad_from_out(yact[o], act, slope);
+            if (dres) dres[o] = g;
+            if (dx) dx[o] = gs * g;
+            if (want_sums) {
+                s1 += g;
+                s2 += g * (x[o] - mu);
+            }
+        }
+    }
+    if (!want_sums) return;
+    s2 *= is;
+    __shared__ float red[16];
+    s1 = rg_block_sum(s1, red);
+    s2 = rg_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        float* o = part + ((int64_t)c * S + s) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
+}
+
 __global__ void bn_bwd_reduce_finalize_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ sum_dy,
                                               float* __restrict__ sum_dy_xhat) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,4 +479,32 @@ extern "C" int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_a
                        y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, dx, dres, total, C, HW,
                        1.f / (float)((int64_t)N * HW), train, stat_is_var, eps, act, slope);
     return rg::check_launch("rg_bn_bwd_apply");
+}
+
+// Eval-mode (running statistics) backward in one pass: dx (may be NULL), dres (may be NULL) and, when sum_dy /
+// sum_dy_xhat are given, the channel sums for dbeta / dgamma (FD-GAN trains the affine parameters of E's and D_id's
+// frozen BatchNorms: FD/fdgan/model.py:72-85).
+extern "C" int rg_bn_eval_bwd(const float* x, const float* dy, const float* y_act, const float* running_mean,
+                              const float* running_var, const float* gamma, float* dx, float* dres, float* sum_dy,
+                              float* sum_dy_xhat, int N, int C, int HW, float eps, int act, float slope,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    RG_REQUIRE(dy && running_mean && running_var && (dx || dres || sum_dy), "rg_bn_eval_bwd: null tensor");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_bn_eval_bwd: fused activation needs the forward output");
+    const int want = (sum_dy && sum_dy_xhat) ? 1 : 0;
+    RG_REQUIRE(!want || x, "rg_bn_eval_bwd: the channel sums need x");
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    if (want && (!workspace || workspace_bytes < (size_t)C * S * 2 * sizeof(float))) {
+        rg::set_error("rg_bn_eval_bwd: workspace too small");
+        return RG_ERR_WORKSPACE;
+    }
+    float* part = static_cast<float*>(workspace);
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (want ? 12.0 : 8.0) * N * (double)C * HW + (dx ? 4.0 : 0.0) * N * (double)C * HW +
+                                                         (dres ? 4.0 : 0.0) * N * (double)C * HW);
+    hipLaunchKernelGGL(bn_eval_bwd_fused_kernel, dim3(S, C), dim3(256), 0, stream, x, dy, y_act, running_mean,
+                       running_var, gamma, dx, dres, part, N, C, HW, L, eps, act, slope, want);
+    if (want)
+        hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, part, C, S, sum_dy,
+                           sum_dy_xhat);
+    return rg::check_launch("rg_bn_eval_bwd");
 }

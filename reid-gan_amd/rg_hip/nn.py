@@ -202,6 +202,18 @@ class _BatchNorm(RGModule):
     def tb(self, tape, dy, need_dx=True):
         x, y, mean, stat, is_var, train, act, slope, has_res = tape.pop()
         need_affine = tape.wants(self.weight) or tape.wants(self.bias)
+        if not train and is_var:
+            # running statistics: dx does not depend on the channel sums -> one fused pass
+            o1 = tape.grad_out(self.bias) if tape.wants(self.bias) else None
+            o2 = tape.grad_out(self.weight) if tape.wants(self.weight) else None
+            dx, dres, s1, s2 = ops.bn_eval_bwd(x, dy, y, mean, stat, self.weight, self.eps, act, slope,
+                                               need_dx=need_dx or not has_res, need_dres=has_res,
+                                               need_sums=need_affine, out_sum_dy=o1, out_sum_dy_xhat=o2)
+            if tape.wants(self.weight):
+                tape.add_grad(self.weight, s2)
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, s1)
+            return (dx, dres) if has_res else dx
         s1 = s2 = None
         if need_affine or (train and need_dx):
             o1 = tape.grad_out(self.bias) if tape.wants(self.bias) else None

@@ -218,6 +218,23 @@ def bn_bwd_apply(x, dy, y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, train, st
     return dx, dres
 
 
+def bn_eval_bwd(x, dy, y_act, running_mean, running_var, gamma, eps=1e-5, act=ACT_NONE, slope=0.0, need_dx=True,
+                need_dres=False, need_sums=True, out_sum_dy=None, out_sum_dy_xhat=None):
+    """Eval-mode BatchNorm backward in one pass -> (dx, dres, sum_dy, sum_dy_xhat)."""
+    x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    N, C, HW = _nchw(dy)
+    dx = torch.empty_like(dy) if need_dx else None
+    dres = torch.empty_like(dy) if need_dres else None
+    s1 = s2 = None
+    if need_sums:
+        s1 = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+        s2 = out_sum_dy_xhat if out_sum_dy_xhat is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+    ws = workspace(lib.rg_bn_workspace(N, C, HW), dy.device)
+    lib.rg_bn_eval_bwd(_p(x), _p(dy), _p(y_act), _p(running_mean), _p(running_var), _p(gamma), _p(dx), _p(dres), _p(s1),
+                       _p(s2), N, C, HW, eps, act, slope, _p(ws), ws.numel(), _stream())
+    return dx, dres, s1, s2
+
+
 def channel_sum(dy, out=None):
     """sum over N and HW of dy[N][C][HW] (bias gradient)."""
     dy = _chk(dy, "dy")

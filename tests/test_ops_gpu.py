@@ -156,6 +156,13 @@ def test_batchnorm(dev, shape, train):
                                 ops.ACT_RELU, need_dx=True, need_dres=True)
     _close(dx, xd.grad, tol=5e-5, name="bn dx")
     _close(dres, resd.grad, name="bn dres")
+    if not train:       # the fused one-pass eval backward must give the same four results
+        fdx, fdres, f1, f2 = ops.bn_eval_bwd(xg, dy.to(dev), y, rmg, rvg, gamma.to(dev), 1e-5, ops.ACT_RELU,
+                                              need_dx=True, need_dres=True, need_sums=True)
+        _close(fdx, xd.grad, tol=5e-5, name="fused eval dx")
+        _close(fdres, resd.grad, name="fused eval dres")
+        _close(f1, bd.grad, tol=5e-5, name="fused eval dbeta")
+        _close(f2, gd.grad, tol=5e-5, name="fused eval dgamma")
 
 
 def test_activations_and_misc(dev):
