@@ -756,7 +756,8 @@ __global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __res
 // ---------------------------------------------------------------------------------------------
 // VEC: 1x1 / stride 1 / pad 0 with P*Q % 4 == 0 — both operands are [rows][pixels] with the reduction axis
 // contiguous, so each lane loads 4 consecutive pixels of one row (float4) instead of 4 scalar loads.
-template <int BM, int BN, int WM, int WN, bool VEC>
+// VECA: only the dy operand that way (any filter, P*Q % 4 == 0); the im2col operand keeps the scalar gather.
+template <int BM, int BN, int WM, int WN, bool VEC, bool VECA>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
     __shared__ float As[2][BK][T::LDA];
@@ -828,24 +829,26 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
     }
 
     auto load_tile = [&](int kt) {
-        if (VEC) {
+        if (VEC || VECA) {
             const int g = kt * BK + vkq;
             const bool gvalid = g < p.Kg;
             const int img = gvalid ? fdiv(g, p.d_pq) : 0;
             const int pq = g - img * PQ;
             const unsigned ab = gvalid ? (unsigned)(img * p.K * PQ + pq) * 4u : OOB;
-            const unsigned bb = gvalid ? (unsigned)(img * p.C * HW + pq) * 4u : OOB;
 #pragma unroll
             for (int i = 0; i < AVN; ++i) {
                 const float4 t = bload4(rdy, ((ab | avoff[i]) & OOB) ? OOB : ab + avoff[i]);
                 ra[4 * i + 0] = t.x; ra[4 * i + 1] = t.y; ra[4 * i + 2] = t.z; ra[4 * i + 3] = t.w;
             }
+            if (VEC) {
+                const unsigned bb = gvalid ? (unsigned)(img * p.C * HW + pq) * 4u : OOB;
 #pragma unroll
-            for (int i = 0; i < BVN; ++i) {
-                const float4 t = bload4(rx, ((bb | bvoff[i]) & OOB) ? OOB : bb + bvoff[i]);
-                rb[4 * i + 0] = t.x; rb[4 * i + 1] = t.y; rb[4 * i + 2] = t.z; rb[4 * i + 3] = t.w;
+                for (int i = 0; i < BVN; ++i) {
+                    const float4 t = bload4(rx, ((bb | bvoff[i]) & OOB) ? OOB : bb + bvoff[i]);
+                    rb[4 * i + 0] = t.x; rb[4 * i + 1] = t.y; rb[4 * i + 2] = t.z; rb[4 * i + 3] = t.w;
+                }
+                return;
             }
-            return;
         }
         const int g = kt * BK + kk;  // global output-pixel index n*P*Q + p*Q + q
         const bool gvalid = g < p.Kg;
@@ -858,9 +861,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
             h0 = pp * p.SH - p.PH;
             w0 = qq * p.SW - p.PW;
         }
-        const unsigned abase = gvalid ? (unsigned)(img * p.K * PQ + pq) * 4u : OOB;
+        if (!VECA) {
+            const unsigned abase = gvalid ? (unsigned)(img * p.K * PQ + pq) * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i) ra[i] = bload(rdy, (abase | aoff[i]) & OOB ? OOB : abase + aoff[i]);
+            for (int i = 0; i < ACNT; ++i) ra[i] = bload(rdy, (abase | aoff[i]) & OOB ? OOB : abase + aoff[i]);
+        }
         const int xb = img * p.C * HW + h0 * p.W + w0;      // element index of (img, 0, h0, w0); may sit in the padding
         if (nopad) {
 #pragma unroll
@@ -883,12 +888,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
         }
     };
     auto store_tile = [&](int buf, int q) {
-        if (VEC) {
+        if (VEC || VECA) {
 #pragma unroll
             for (int i = 0; i < AVN; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (vrow + 64 * i < BM && in_quarter(4 * i + j, 4 * AVN, q)) As[buf][vkq + j][vrow + 64 * i] = ra[4 * i + j];
+        }
+        if (VEC) {
 #pragma unroll
             for (int i = 0; i < BVN; ++i)
 #pragma unroll
@@ -896,9 +903,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
                     if (vrow + 64 * i < BN && in_quarter(4 * i + j, 4 * BVN, q)) Bs[buf][vkq + j][vrow + 64 * i] = rb[4 * i + j];
             return;
         }
+        if (!VECA) {
 #pragma unroll
-        for (int i = 0; i < ACNT; ++i)
-            if (in_quarter(i, ACNT, q)) As[buf][kk][r0 + 16 * i] = ra[i];
+            for (int i = 0; i < ACNT; ++i)
+                if (in_quarter(i, ACNT, q)) As[buf][kk][r0 + 16 * i] = ra[i];
+        }
 #pragma unroll
         for (int i = 0; i < BCNT; ++i)
             if (in_quarter(i, BCNT, q)) Bs[buf][kk][r0 + 16 * i] = rb[i];
@@ -1261,8 +1270,9 @@ struct WgradPlan {
 };
 static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     WgradPlan pl;
+    // the reduction (N*P*Q) is long, so parallelism comes from split-K: always take the largest tile that fits
+    // (a 64x64 tile issues 2x the LDS reads and 4x the loader instructions per MFMA of the 128x128 one)
     pl.tile = (M <= 32) ? 3 : ((M <= 64 || Ng <= 64) ? 2 : 0);
-    if (pl.tile == 0 && (int64_t)rg::cdiv(M, 128) * rg::cdiv(Ng, 128) < 64) pl.tile = 2;
     pl.m_tiles = rg::cdiv(M, kTileBM[pl.tile]);
     pl.n_tiles = rg::cdiv(Ng, kTileBN[pl.tile]);
     const int64_t nk = rg::cdiv64(Kg, BK);
@@ -1315,22 +1325,19 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     const dim3 grid(p.m_tiles * p.n_tiles, 1, pl.splits);
     {
         rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
-        const bool vec = KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0 && ((P * Q) % 4 == 0) &&
-                         (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0);
+        const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+        const bool veca = al && ((P * Q) % 4 == 0);
+        const bool vec = veca && KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0;
+#define RG_WGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                        \
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, true, true>), grid, dim3(NT), 0, stream, p); \
+    else if (veca) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NT), 0, stream, p); \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NT), 0, stream, p)
         switch (pl.tile) {
-            case 0:
-                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(NT), 0, stream, p);
-                else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(NT), 0, stream, p);
-                break;
-            case 2:
-                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true>), grid, dim3(NT), 0, stream, p);
-                else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false>), grid, dim3(NT), 0, stream, p);
-                break;
-            default:
-                if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4, true>), grid, dim3(NT), 0, stream, p);
-                else hipLaunchKernelGGL((conv_wgrad_kernel<32, 256, 1, 4, false>), grid, dim3(NT), 0, stream, p);
-                break;
+            case 0: RG_WGRAD_LAUNCH(128, 128, 2, 2); break;
+            case 2: RG_WGRAD_LAUNCH(64, 64, 2, 2); break;
+            default: RG_WGRAD_LAUNCH(32, 256, 1, 4); break;
         }
+#undef RG_WGRAD_LAUNCH
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
