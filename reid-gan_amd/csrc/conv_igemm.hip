@@ -954,13 +954,26 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
 }
 
 // dw[i] = sum_s ws[s][i]; with rsc != 0 the partial columns are (r,s)-major (n' = rs*C + c) and are written back in
-// the checkpoint order [K][C][RS].  Deterministic (fixed summation order).
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits,
-                                     int rsc, int C, int RS) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
+// the checkpoint order [K][C][RS].  Deterministic (fixed summation tree).  64 outputs x 4 split lanes per
+// workgroup: small filter tensors with hundreds of splits stay parallel instead of one long serial chain per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            int64_t n, int splits, int rsc, int C, int RS) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < n) {
+        int k = ty;
+        for (; k + 4 < splits; k += 8) {
+            s0 += ws[(int64_t)k * n + i];
+            s1 += ws[(int64_t)(k + 4) * n + i];
+        }
+        if (k < splits) s0 += ws[(int64_t)k * n + i];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty != 0 || i >= n) return;
+    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
     if (!rsc) {
         out[i] = s;
         return;
@@ -1341,7 +1354,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 256)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
                                static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
         }
     }
