@@ -115,6 +115,23 @@ def log(*a):
     print("[bench %s]" % time.strftime("%H:%M:%S"), *a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(launches_per_step):
+    """HBM bytes per conv launch from the committed PMC passes (profiles/r01_pmc_traffic.json; produced on the GPU
+    box by tools/prof_summary.py + tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this script).  PMC counters cannot be read from inside the process, so the figure is not live; None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            fam = json.load(f)["families"]["conv"]
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC pass committed"
+    per_step = fam["read_bytes_per_step"] + fam["write_bytes_per_step"]
+    return round(per_step / max(launches_per_step, 1)), ("profiles/r01_pmc_traffic.json: %.1f GB read + %.1f GB written per "
+                                                         "step by the conv family incl. split-K finish/reduce and KRSC "
+                                                         "repack kernels" % (fam["read_bytes_per_step"] / 1e9,
+                                                                             fam["write_bytes_per_step"] / 1e9))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,8 +213,10 @@ def main():
         fl = sum(f["flops"] for f in conv)
         calls = sum(f["calls"] for f in conv)
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(calls // args.profile_steps)
         roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                 "kernel": "conv implicit-GEMM family (conv_fwd/dgrad/wgrad_kernel, v_mfma_f32_32x32x2_f32)",
                 "launches_per_step": calls // args.profile_steps,
                 "avg_launch_us": round(1e3 * ms / max(calls, 1), 2),

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Fold the FETCH_SIZE / WRITE_SIZE summaries (tools/prof_summary.py) of two separate rocprofv3 --pmc passes into
+per-family HBM traffic.  Units and corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950
+FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled; WRITE_SIZE is exact.
+
+usage: pmc_traffic.py <pmc_fetch_size.csv> <pmc_write_size.csv> <steps in each pass> <out.json>"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+FAMILIES = (("conv", ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_splitk_finish", "splitk_reduce", "weights_to_krsc")),
+            ("norm", ("bn_",)), ("optim", ("adam", "sgd")), ("pool", ("maxpool", "global_avgpool", "gem_")))
+
+
+def fam(k):
+    for f, pre in FAMILIES:
+        if k.startswith(pre):
+            return f
+    return "other"
+
+
+def main():
+    fpath, wpath, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    rd, wr, n = defaultdict(float), defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(fpath)):
+        rd[fam(r["kernel"])] += float(r["FETCH_SIZE_total"]) * 1024 * 2
+        n[fam(r["kernel"])] += int(r["launches"])
+    for r in csv.DictReader(open(wpath)):
+        wr[fam(r["kernel"])] += float(r["WRITE_SIZE_total"]) * 1024
+    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
+                     "--steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline",
+           "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE exact",
+           "steps_per_pass": steps, "families": {}}
+    for f in rd:
+        res["families"][f] = {"launches_per_step": n[f] / steps, "read_bytes_per_step": rd[f] / steps,
+                              "write_bytes_per_step": wr[f] / steps,
+                              "bytes_per_launch": (rd[f] + wr[f]) / max(n[f], 1)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["families"]["conv"]))
+
+
+if __name__ == "__main__":
+    main()
