@@ -122,6 +122,40 @@ int rg_l2norm_rows_bwd(const float* y, const float* dy, const float* norm, float
 int rg_copy_channels(const float* src, float* dst, int N, int Cc, int HW, int Cs, int sc0, int Cd, int dc0,
                      int accumulate, rg_stream_t stream);
 
+/* my_resize / my_normalize / my_transform, CC/clustercontrast/utils/data/diff_augs.py:6-16: bicubic (A = -0.75,
+ * align_corners = False, clamped border taps) resize [N,C,H,W] -> [N,C,OH,OW] fused with (v - mean[c]) / std[c];
+ * mean/std are device arrays of C floats or both NULL (resize only); OH == H and OW == W normalises only.
+ * The backward is the exact adjoint, gathered per input pixel (deterministic). */
+int rg_bicubic_normalize_fwd(const float* x, float* y, int N, int C, int H, int W, int OH, int OW, const float* mean,
+                             const float* stdv, rg_stream_t stream);
+int rg_bicubic_normalize_bwd(const float* dy, float* dx, int N, int C, int H, int W, int OH, int OW, const float* stdv,
+                             rg_stream_t stream);
+
+/* ---- dual_gan blocks (CC/dual_gan/models/base_function.py, PTM.py) ---------------------------- */
+/* nn.AvgPool2d(k, k) of the ResBlockEncoder shortcuts, base_function.py:372-420; P = H / k, Q = W / k */
+int rg_avgpool2d_fwd(const float* x, float* y, int N, int C, int H, int W, int k, rg_stream_t stream);
+int rg_avgpool2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int k, rg_stream_t stream);
+/* nn.ReflectionPad2d(pad) of the Output block, base_function.py:423-443; y is [N,C,H+2pad,W+2pad] */
+int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, rg_stream_t stream);
+int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int pad, rg_stream_t stream);
+/* torch.nn.utils.spectral_norm (base_function.py:121-126; every ResDiscriminator conv, networks.py:917-955) on the
+ * filter viewed as W[K][M]: training != 0 runs one power iteration in place on u[K], v[M] (eps-clamped norms), then
+ * sigma = u.(W v); writes w_sn = W / sigma and sigma[0] = sigma, sigma[1] = 1 / sigma (device, 2 floats).
+ * K <= 1024, M <= 12288.  Backward: dw (+)= (dw_sn - (sum dw_sn * w_sn) u v^T) / sigma with the forward's u, v. */
+int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, int K, int M, int training,
+                         float eps, rg_stream_t stream);
+int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
+                         float* dw, int K, int M, int accumulate, rg_stream_t stream);
+/* Batched strided fp32 GEMM (MFMA) for nn.MultiheadAttention inside CAB / TTB, PTM.py:162-247:
+ * C[b0][b1][m][n] = alpha * sum_k A[b0][b1][m][k] B[b0][b1][k][n] + beta * C; all strides in elements, so Q^T K,
+ * P V and the backward products run on [B][C][L] token maps without permutes. */
+int rg_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t a_ms, int64_t a_ks, int64_t b_ks,
+             int64_t b_ns, int64_t c_ms, int64_t c_ns, int batch0, int batch1, int64_t a_b0, int64_t a_b1, int64_t b_b0,
+             int64_t b_b1, int64_t c_b0, int64_t c_b1, float alpha, float beta, rg_stream_t stream);
+/* y[r][:] = softmax(scale * x[r][:]) and ds = scale * p * (dp - sum(dp * p)); in place allowed */
+int rg_softmax_rows_fwd(const float* x, float* y, int rows, int cols, float scale, rg_stream_t stream);
+int rg_softmax_rows_bwd(const float* p, const float* dp, float* ds, int rows, int cols, float scale, rg_stream_t stream);
+
 /* ---- pooling -------------------------------------------------------------------------------- */
 int rg_maxpool2d_fwd(const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W, int KH, int KW,
                      int SH, int SW, int PH, int PW, int P, int Q, rg_stream_t stream);

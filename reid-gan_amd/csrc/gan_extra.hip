@@ -1,0 +1,239 @@
+// Small HBM/latency-bound kernels of the dual_gan networks (CC/dual_gan/models/base_function.py):
+//   nn.AvgPool2d(2, 2) of ResBlockEncoder(Optimized) shortcuts            :372-420
+//   nn.ReflectionPad2d(1) of the Output block                             :423-443
+//   torch.nn.utils.spectral_norm on every discriminator conv              :121-126, networks.py:917-955
+#include "rg_common.h"
+
+namespace {
+
+static unsigned grid_for(int64_t items) {
+    int64_t g = rg::cdiv64(items, 256);
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+#define RG_GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---- average pooling, kernel == stride == k, no padding ------------------------------------------------------
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int k, int P, int Q,
+                                   int64_t total) {
+    const float inv = 1.f / (float)(k * k);
+    RG_GRID_STRIDE(i, total) {
+        const int q = (int)(i % Q);
+        const int64_t r = i / Q;
+        const int pp = (int)(r % P);
+        const int64_t nc = r / P;
+        const float* src = x + (nc * H + (int64_t)pp * k) * W + (int64_t)q * k;
+        float s = 0.f;
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) s += src[(int64_t)a * W + b];
+        y[i] = s * inv;
+    }
+}
+
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int k, int P, int Q,
+                                   int64_t total) {
+    const float inv = 1.f / (float)(k * k);
+    RG_GRID_STRIDE(i, total) {
+        const int w = (int)(i % W);
+        const int64_t r = i / W;
+        const int h = (int)(r % H);
+        const int64_t nc = r / H;
+        const int pp = h / k, q = w / k;
+        dx[i] = (pp < P && q < Q) ? dy[(nc * P + pp) * Q + q] * inv : 0.f;
+    }
+}
+
+// ---- reflection padding --------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect(int t, int len) {
+    if (t < 0) t = -t;
+    if (t >= len) t = 2 * (len - 1) - t;
+    return t;
+}
+
+__global__ void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int pad, int OH,
+                                       int OW, int64_t total) {
+    RG_GRID_STRIDE(i, total) {
+        const int ow = (int)(i % OW);
+        const int64_t r = i / OW;
+        const int oh = (int)(r % OH);
+        const int64_t nc = r / OH;
+        y[i] = x[(nc * H + reflect(oh - pad, H)) * W + reflect(ow - pad, W)];
+    }
+}
+
+// gather form of the adjoint: input (h, w) collects its own copy plus the mirrored border copies
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int pad, int OH,
+                                       int OW, int64_t total) {
+    RG_GRID_STRIDE(i, total) {
+        const int w = (int)(i % W);
+        const int64_t r = i / W;
+        const int h = (int)(r % H);
+        const int64_t nc = r / H;
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = h + pad;
+        if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+        if (h <= H - 2 && h >= H - 1 - pad) hs[nh++] = pad + 2 * (H - 1) - h;
+        ws[nw++] = w + pad;
+        if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+        if (w <= W - 2 && w >= W - 1 - pad) ws[nw++] = pad + 2 * (W - 1) - w;
+        float s = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) s += dy[(nc * OH + hs[a]) * OW + ws[b]];
+        dx[i] = s;
+    }
+}
+
+// ---- spectral norm ---------------------------------------------------------------------------------------------
+// One workgroup per weight matrix W[K][M] (discriminator filters: K <= 128, M <= 2048, <= 1 MB).
+// training: v <- normalize(W^T u), u <- normalize(W v) (one power iteration, eps-clamped norms, as
+// torch.nn.utils.spectral_norm with n_power_iterations = 1), then sigma = u . (W v).
+// sigma is written to sigma_out[0] and 1/sigma to sigma_out[1]; the scaled weight comes from the second kernel.
+constexpr int SN_THREADS = 1024;
+constexpr int SN_MAX_M = 12288;         // v (and W^T u) live in LDS
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const float* __restrict__ w, float* __restrict__ u,
+                                                                        float* __restrict__ v, float* __restrict__ sigma_out,
+                                                                        int K, int M, int training, float eps) {
+    __shared__ float vs[SN_MAX_M];
+    __shared__ float us[1024];
+    __shared__ float ss[1024];
+    __shared__ float red[32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int k = tid; k < K; k += SN_THREADS) us[k] = u[k];
+    __syncthreads();
+    if (training) {
+        // t = W^T u (threads along m: coalesced rows), v = t / max(|t|, eps)
+        float part = 0.f;
+        for (int m = tid; m < M; m += SN_THREADS) {
+            float t = 0.f;
+            for (int k = 0; k < K; ++k) t += w[(int64_t)k * M + m] * us[k];
+            vs[m] = t;
+            part += t * t;
+        }
+        const float nrm = sqrtf(rg_block_sum(part, red));
+        const float inv = 1.f / fmaxf(nrm, eps);
+        for (int m = tid; m < M; m += SN_THREADS) {
+            const float t = vs[m] * inv;
+            vs[m] = t;
+            v[m] = t;
+        }
+    } else {
+        for (int m = tid; m < M; m += SN_THREADS) vs[m] = v[m];
+    }
+    __syncthreads();
+    // s = W v: one wave per row
+    for (int k = wid; k < K; k += SN_THREADS / 64) {
+        float s = 0.f;
+        for (int m = lane; m < M; m += 64) s += w[(int64_t)k * M + m] * vs[m];
+        s = rg_wave_sum(s);
+        if (lane == 0) ss[k] = s;
+    }
+    __syncthreads();
+    float dotp = 0.f;
+    if (training) {
+        float part = 0.f;
+        for (int k = tid; k < K; k += SN_THREADS) part += ss[k] * ss[k];
+        const float nrm = sqrtf(rg_block_sum(part, red));
+        const float inv = 1.f / fmaxf(nrm, eps);
+        for (int k = tid; k < K; k += SN_THREADS) {
+            const float un = ss[k] * inv;
+            u[k] = un;
+            dotp += un * ss[k];
+        }
+    } else {
+        for (int k = tid; k < K; k += SN_THREADS) dotp += us[k] * ss[k];
+    }
+    const float sigma = rg_block_sum(dotp, red);
+    if (tid == 0) {
+        sigma_out[0] = sigma;
+        sigma_out[1] = 1.f / sigma;
+    }
+}
+
+__global__ void scale_by_device_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ s,
+                                              int64_t n) {
+    const float f = s[0];
+    RG_GRID_STRIDE(i, n) y[i] = x[i] * f;
+}
+
+// dW = (dWsn - (sum dWsn * Wsn) u v^T) / sigma      (u, v constants of the forward)
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_bwd_kernel(const float* __restrict__ dwsn,
+                                                                      const float* __restrict__ wsn,
+                                                                      const float* __restrict__ u, const float* __restrict__ v,
+                                                                      const float* __restrict__ sigma, float* __restrict__ dw,
+                                                                      int K, int M, int accumulate) {
+    __shared__ float red[32];
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)K * M;
+    float part = 0.f;
+    for (int64_t i = tid; i < n; i += SN_THREADS) part += dwsn[i] * wsn[i];
+    const float c = rg_block_sum(part, red);
+    const float inv = sigma[1];
+    for (int64_t i = tid; i < n; i += SN_THREADS) {
+        const int k = (int)(i / M), m = (int)(i - (int64_t)k * M);
+        const float g = (dwsn[i] - c * u[k] * v[m]) * inv;
+        dw[i] = accumulate ? dw[i] + g : g;
+    }
+}
+
+}  // namespace
+
+extern "C" int rg_avgpool2d_fwd(const float* x, float* y, int N, int C, int H, int W, int k, hipStream_t stream) {
+    RG_REQUIRE(x && y && N > 0 && C > 0 && k > 0 && H >= k && W >= k, "rg_avgpool2d_fwd: bad arguments");
+    const int P = H / k, Q = W / k;
+    const int64_t total = (int64_t)N * C * P * Q;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * (total + (double)N * C * H * W));
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, H, W, k, P, Q, total);
+    return rg::check_launch("rg_avgpool2d_fwd");
+}
+
+extern "C" int rg_avgpool2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int k, hipStream_t stream) {
+    RG_REQUIRE(dy && dx && N > 0 && C > 0 && k > 0 && H >= k && W >= k, "rg_avgpool2d_bwd: bad arguments");
+    const int P = H / k, Q = W / k;
+    const int64_t total = (int64_t)N * C * H * W;
+    rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * (total + (double)N * C * P * Q));
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, H, W, k, P, Q, total);
+    return rg::check_launch("rg_avgpool2d_bwd");
+}
+
+extern "C" int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, hipStream_t stream) {
+    RG_REQUIRE(x && y && N > 0 && C > 0 && pad >= 0 && pad < H && pad < W, "rg_reflection_pad2d_fwd: pad must be < H and W");
+    const int OH = H + 2 * pad, OW = W + 2 * pad;
+    const int64_t total = (int64_t)N * C * OH * OW;
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, total);
+    return rg::check_launch("rg_reflection_pad2d_fwd");
+}
+
+extern "C" int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int pad, hipStream_t stream) {
+    RG_REQUIRE(dy && dx && N > 0 && C > 0 && pad >= 0 && pad < H && pad < W, "rg_reflection_pad2d_bwd: pad must be < H and W");
+    const int OH = H + 2 * pad, OW = W + 2 * pad;
+    const int64_t total = (int64_t)N * C * H * W;
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, total);
+    return rg::check_launch("rg_reflection_pad2d_bwd");
+}
+
+extern "C" int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, int K, int M,
+                                    int training, float eps, hipStream_t stream) {
+    RG_REQUIRE(w && u && v && w_sn && sigma && K > 0 && M > 0, "rg_spectral_norm_fwd: bad arguments");
+    RG_REQUIRE(K <= 1024 && M <= SN_MAX_M, "rg_spectral_norm_fwd: matrix %d x %d exceeds the single-workgroup limits (1024 x %d)",
+               K, M, SN_MAX_M);
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 12.0 * K * M);
+    hipLaunchKernelGGL(spectral_norm_power_kernel, dim3(1), dim3(SN_THREADS), 0, stream, w, u, v, sigma, K, M, training, eps);
+    const int64_t n = (int64_t)K * M;
+    hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w, w_sn, sigma + 1, n);
+    return rg::check_launch("rg_spectral_norm_fwd");
+}
+
+extern "C" int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
+                                    float* dw, int K, int M, int accumulate, hipStream_t stream) {
+    RG_REQUIRE(dw_sn && w_sn && u && v && sigma && dw && K > 0 && M > 0, "rg_spectral_norm_bwd: bad arguments");
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 16.0 * K * M);
+    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(SN_THREADS), 0, stream, dw_sn, w_sn, u, v, sigma, dw, K, M,
+                       accumulate);
+    return rg::check_launch("rg_spectral_norm_bwd");
+}

@@ -337,6 +337,107 @@ def copy_channels(src, dst, c_count, src_c0, dst_c0, accumulate=False):
     return dst
 
 
+def bicubic_normalize_fwd(x, size, mean=None, std=None):
+    """[N,C,H,W] -> [N,C,OH,OW] bicubic (align_corners False) then (v - mean[c]) / std[c]; mean/std device [C] or None."""
+    x = _chk(x, "x")
+    if x.dim() != 4:
+        raise ValueError("bicubic_normalize: expected NCHW")
+    N, C, H, W = x.shape
+    OH, OW = int(size[0]), int(size[1])
+    y = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device)
+    lib.rg_bicubic_normalize_fwd(_p(x), _p(y), N, C, H, W, OH, OW, _p(mean) if mean is not None else None,
+                                 _p(std) if std is not None else None, _stream())
+    return y
+
+
+def bicubic_normalize_bwd(dy, in_hw, std=None):
+    dy = _chk(dy, "dy")
+    N, C, OH, OW = dy.shape
+    H, W = int(in_hw[0]), int(in_hw[1])
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    lib.rg_bicubic_normalize_bwd(_p(dy), _p(dx), N, C, H, W, OH, OW, _p(std) if std is not None else None, _stream())
+    return dx
+
+
+def avgpool2d_fwd(x, k=2):
+    x = _chk(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // k, W // k), dtype=torch.float32, device=x.device)
+    lib.rg_avgpool2d_fwd(_p(x), _p(y), N, C, H, W, k, _stream())
+    return y
+
+
+def avgpool2d_bwd(dy, x_shape, k=2):
+    dy = _chk(dy, "dy")
+    N, C, H, W = x_shape
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    lib.rg_avgpool2d_bwd(_p(dy), _p(dx), N, C, H, W, k, _stream())
+    return dx
+
+
+def reflection_pad2d_fwd(x, pad):
+    x = _chk(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=torch.float32, device=x.device)
+    lib.rg_reflection_pad2d_fwd(_p(x), _p(y), N, C, H, W, pad, _stream())
+    return y
+
+
+def reflection_pad2d_bwd(dy, pad):
+    dy = _chk(dy, "dy")
+    N, C, OH, OW = dy.shape
+    H, W = OH - 2 * pad, OW - 2 * pad
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    lib.rg_reflection_pad2d_bwd(_p(dy), _p(dx), N, C, H, W, pad, _stream())
+    return dx
+
+
+def spectral_norm_fwd(w, u, v, training=True, eps=1e-12):
+    """One power iteration in place on u, v (training) and W / sigma; returns (w_sn, sigma[2] = (sigma, 1/sigma))."""
+    w = _chk(w, "w")
+    K = w.shape[0]
+    M = w.numel() // K
+    if u.numel() != K or v.numel() != M or not (u.is_contiguous() and v.is_contiguous()):
+        raise ValueError("spectral_norm: u / v do not match the weight matrix %d x %d" % (K, M))
+    w_sn = torch.empty_like(w)
+    sigma = torch.empty(2, dtype=torch.float32, device=w.device)
+    lib.rg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(w_sn), _p(sigma), K, M, int(bool(training)), eps, _stream())
+    return w_sn, sigma
+
+
+def spectral_norm_bwd(dw_sn, w_sn, u, v, sigma, out=None, accumulate=False):
+    dw_sn = _chk(dw_sn, "dw_sn")
+    K = w_sn.shape[0]
+    M = w_sn.numel() // K
+    dw = out if out is not None else torch.empty_like(w_sn)
+    lib.rg_spectral_norm_bwd(_p(dw_sn), _p(w_sn), _p(u), _p(v), _p(sigma), _p(dw), K, M, int(accumulate), _stream())
+    return dw
+
+
+def bgemm(A, B, C, M, N, K, a_str, b_str, c_str, batch, a_b, b_b, c_b, alpha=1.0, beta=0.0):
+    """C[b0][b1] = alpha A[b0][b1] . B[b0][b1] + beta C; a_str = (row, k) strides of A, b_str = (k, col) of B,
+    c_str = (row, col) of C, batch = (n0, n1), *_b = (stride b0, stride b1); all in elements.  Tensors are base buffers."""
+    lib.rg_bgemm(_p(A), _p(B), _p(C), M, N, K, a_str[0], a_str[1], b_str[0], b_str[1], c_str[0], c_str[1], batch[0], batch[1],
+                 a_b[0], a_b[1], b_b[0], b_b[1], c_b[0], c_b[1], alpha, beta, _stream())
+    return C
+
+
+def softmax_rows_fwd(x, scale=1.0, out=None):
+    x = _chk(x, "x")
+    cols = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    lib.rg_softmax_rows_fwd(_p(x), _p(y), x.numel() // cols, cols, scale, _stream())
+    return y
+
+
+def softmax_rows_bwd(p, dp, scale=1.0, out=None):
+    p, dp = _chk(p, "p"), _chk(dp, "dp")
+    cols = p.shape[-1]
+    ds = out if out is not None else torch.empty_like(p)
+    lib.rg_softmax_rows_bwd(_p(p), _p(dp), _p(ds), p.numel() // cols, cols, scale, _stream())
+    return ds
+
+
 def cat_channels(tensors):
     """torch.cat(tensors, dim=1) for NCHW (or NC) tensors."""
     N = tensors[0].shape[0]

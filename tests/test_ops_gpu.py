@@ -345,3 +345,137 @@ def test_optimizers(dev):
         opt.step()
         ops.sgd_step(pg, gr.to(dev), buf, 0.01, 0.9, 1e-4, t == 0)
     _close(pg, pr, name="sgd")
+
+
+@pytest.mark.parametrize("case", [
+    (2, 3, 128, 64, 256, 128, True),     # my_transform of the joint step
+    (2, 3, 128, 64, 256, 128, False),    # my_resize
+    (1, 3, 16, 8, 16, 8, True),          # my_normalize only
+    (2, 2, 9, 7, 20, 23, False),         # odd, non-integer scale
+    (1, 3, 32, 16, 12, 10, True),        # down-sampling without antialias (same formula)
+])
+def test_bicubic_normalize(dev, case):
+    """diff_augs.my_resize / my_normalize / my_transform vs F.interpolate(bicubic, align_corners=False) + affine."""
+    ops = _ops()
+    N, C, H, W, OH, OW, norm = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(N, C, H, W, generator=g)
+    dy = torch.randn(N, C, OH, OW, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406][:C])
+    std = torch.tensor([0.229, 0.224, 0.225][:C])
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, size=(OH, OW), mode="bicubic", align_corners=False) if (OH, OW) != (H, W) else xr * 1.0
+    if norm:
+        yr = (yr - mean.double().view(1, C, 1, 1)) / std.double().view(1, C, 1, 1)
+    yr.backward(dy.double())
+    m, s = (mean.to(dev), std.to(dev)) if norm else (None, None)
+    y = ops.bicubic_normalize_fwd(x.to(dev), (OH, OW), m, s)
+    dx = ops.bicubic_normalize_bwd(dy.to(dev), (H, W), s)
+    _close(y, yr, name="bicubic fwd")
+    _close(dx, xr.grad, name="bicubic bwd")
+
+
+def test_diff_augs_api(dev):
+    from clustercontrast.utils.data.diff_augs import my_normalize, my_resize, my_transform
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 128, 64, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    out = my_transform(xd)
+    assert out.shape == (2, 3, 256, 128)
+    ref = my_normalize(my_resize(x.to(dev)))
+    _close(out, ref, name="my_transform == my_normalize(my_resize)")
+    out.sum().backward()
+    xr = x.double().requires_grad_(True)
+    std = torch.tensor([0.229, 0.224, 0.225]).double().view(1, 3, 1, 1)
+    (F.interpolate(xr, size=(256, 128), mode="bicubic", align_corners=False) / std).sum().backward()
+    _close(xd.grad, xr.grad, name="my_transform grad")
+    assert my_resize(x[0].to(dev), (64, 32)).shape == (3, 64, 32)
+    with pytest.raises(ValueError):
+        my_normalize(torch.rand(1, 4, 8, 8).to(dev))
+
+
+def test_avgpool_reflection_pad(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 5, 12, 10, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    _close(ops.avgpool2d_fwd(x.to(dev), 2), yr, name="avgpool fwd")
+    _close(ops.avgpool2d_bwd(dy.to(dev), x.shape, 2), xr.grad, name="avgpool bwd")
+    x2 = torch.randn(2, 3, 7, 9, generator=g)          # odd sizes: the last row / column is dropped
+    _close(ops.avgpool2d_fwd(x2.to(dev), 2), F.avg_pool2d(x2.double(), 2, 2), name="avgpool odd")
+    for pad in (1, 2):
+        xr = x.double().requires_grad_(True)
+        yr = F.pad(xr, (pad,) * 4, mode="reflect")
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy.double())
+        _close(ops.reflection_pad2d_fwd(x.to(dev), pad), yr, name="reflect fwd")
+        _close(ops.reflection_pad2d_bwd(dy.to(dev), pad), xr.grad, name="reflect bwd")
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 3, 3), (64, 32, 4, 4), (1, 128, 1, 1), (128, 128, 4, 4)])
+def test_spectral_norm(dev, shape):
+    """torch.nn.utils.spectral_norm (one power iteration per training forward) — weight, u, v and the gradient."""
+    ops = _ops()
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(shape[1], shape[0], shape[2:], bias=False).double()
+    ref = torch.nn.utils.spectral_norm(conv)
+    w0 = ref.weight_orig.detach().clone()
+    u = ref.weight_u.detach().clone().float().to(dev)
+    v = ref.weight_v.detach().clone().float().to(dev)
+    wd = w0.float().to(dev)
+    for it in range(3):                                   # successive forwards keep iterating u, v
+        ref.train()
+        x = torch.randn(2, shape[1], 8, 8, dtype=torch.float64)
+        y = ref(x)
+        w_sn, sigma = ops.spectral_norm_fwd(wd, u, v, True)
+        _close(w_sn, ref.weight, tol=1e-5, name="w_sn it%d" % it)
+        _close(u, ref.weight_u, tol=1e-5, name="u")
+        _close(v, ref.weight_v, tol=1e-5, name="v")
+    gw = torch.randn(shape, dtype=torch.float64)
+    ref.zero_grad()
+    (ref.weight * gw).sum().backward()
+    dw = ops.spectral_norm_bwd(gw.float().to(dev), w_sn, u, v, sigma)
+    _close(dw, ref.weight_orig.grad, tol=1e-5, name="dw")
+    ref.eval()                                            # eval: no iteration, same u / v
+    ref(x)
+    u2, v2 = u.clone(), v.clone()
+    w_sn2, _ = ops.spectral_norm_fwd(wd, u2, v2, False)
+    _close(w_sn2, ref.weight, tol=1e-5, name="w_sn eval")
+    assert torch.equal(u2, u) and torch.equal(v2, v)
+
+
+def test_bgemm_and_softmax(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, H, D, L, S = 3, 2, 40, 50, 70
+    q = torch.randn(B, H * D, L, generator=g)
+    k = torch.randn(B, H * D, S, generator=g)
+    v = torch.randn(B, H * D, S, generator=g)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    # scores[b,h,l,s] = sum_d q[b,hD+d,l] k[b,hD+d,s]
+    sc = torch.empty(B, H, L, S, device=dev)
+    ops.bgemm(qd, kd, sc, L, S, D, (1, L), (S, 1), (S, 1), (B, H), (H * D * L, D * L), (H * D * S, D * S), (H * L * S, L * S))
+    ref = torch.einsum("bhdl,bhds->bhls", q.double().view(B, H, D, L), k.double().view(B, H, D, S))
+    _close(sc, ref, name="QtK")
+    scale = 1.0 / math.sqrt(D)
+    p = ops.softmax_rows_fwd(sc, scale)
+    pref = torch.softmax(ref * scale, dim=-1)
+    _close(p, pref, name="softmax")
+    # out[b,hD+d,l] = sum_s v[b,hD+d,s] p[b,h,l,s]
+    o = torch.empty(B, H * D, L, device=dev)
+    ops.bgemm(vd, p, o, D, L, S, (S, 1), (1, S), (L, 1), (B, H), (H * D * S, D * S), (H * L * S, L * S), (H * D * L, D * L))
+    oref = torch.einsum("bhds,bhls->bhdl", v.double().view(B, H, D, S), pref).reshape(B, H * D, L)
+    _close(o, oref, name="PV")
+    # alpha / beta accumulate
+    o2 = o.clone()
+    ops.bgemm(vd, p, o2, D, L, S, (S, 1), (1, S), (L, 1), (B, H), (H * D * S, D * S), (H * L * S, L * S), (H * D * L, D * L),
+              alpha=0.5, beta=2.0)
+    _close(o2, 2.5 * oref, name="alpha beta")
+    dp = torch.randn(B, H, L, S, generator=g)
+    ds = ops.softmax_rows_bwd(p, dp.to(dev), scale)
+    xr = (ref * 1.0).requires_grad_(True)
+    torch.softmax(xr * scale, dim=-1).backward(dp.double())
+    _close(ds, xr.grad, name="softmax bwd")
