@@ -1,0 +1,164 @@
+"""dual_gan generators / discriminator on the HIP kernels.
+
+Mirror of CC/dual_gan/models/networks.py: `define_G` (:14-33), `define_D` (:36-38), `PoseGenerator1` (:639-738),
+`ResDiscriminator` (:917-955) — same constructor arguments, attribute names (`block0`, `encoder{i}`, `feature_block`,
+`PCTM`, `decoder{i}`, `outconv`, `conv`) and state_dict keys.  Every network is ONE autograd node (rg_hip.tape) running
+the block programs of base_function.py / PTM.py.
+"""
+from __future__ import absolute_import
+
+import torch
+from torch import nn
+
+from rg_hip import nn as rnn
+from rg_hip import ops
+from rg_hip.tape import RGModule
+from .base_function import (EncoderBlock, EncoderBlockOptimized, FeatureAdaptBlock1, Output, ResBlockDecoder,
+                            ResBlockEncoder, ResBlockEncoderOptimized, SpectralNorm, get_nonlinearity_layer,
+                            get_norm_layer, init_net, _slope)
+from .PTM import PCTM, PTM  # noqa: F401
+
+
+###############################################################################
+# Functions
+###############################################################################
+def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='batch', activation='ReLU',
+             use_spect=True, use_coord=False, output_nc=3, num_blocks=3, affine=True, nhead=2, num_CABs=2, num_TTBs=2):
+    print(opt.model_gen)
+    if opt.model_gen == 'Pose':
+        netG = PoseGenerator1(ngf, pose_nc, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc,
+                              affine, nhead, num_CABs, num_TTBs)
+    elif opt.model_gen in ('DPTN', 'AE', 'DEC', 'FD', 'PoseAE'):
+        raise NotImplementedError("generator '%s' is not built yet on the HIP path (only 'Pose', the generator of the "
+                                  "joint training step)" % opt.model_gen)
+    else:
+        raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
+    return init_net(netG, opt.init_type)
+
+
+def define_D(opt, input_nc=3, ndf=64, img_f=1024, layers=3, norm='none', activation='LeakyReLU', use_spect=True,):
+    netD = ResDiscriminator(input_nc, ndf, img_f, layers, norm, activation, use_spect)
+    return init_net(netD, opt.init_type)
+
+
+def print_network(net):
+    if isinstance(net, list):
+        net = net[0]
+    num_params = 0
+    for param in net.parameters():
+        num_params += param.numel()
+    print('Total number of parameters: %d' % num_params)
+
+
+##############################################################################
+# Generator
+##############################################################################
+class PoseGenerator1(RGModule):
+    """Pose encoder -> PCTM(pose tokens attend to the adapted ReID feature map) -> residual decoder with skips
+    (networks.py:639-738).  forward(reid_f [B, 2048, h, w], source_pose [B, pose_nc, H, W]) -> image [B, 3, H, W]."""
+
+    def __init__(self, ngf=64, pose_nc=18, img_f=256, layers=3, norm='batch', activation='ReLU', use_spect=True,
+                 use_coord=False, output_nc=3, affine=True, nhead=2, num_CABs=2, num_TTBs=2):
+        super(PoseGenerator1, self).__init__()
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        input_nc = pose_nc
+
+        self.block0 = EncoderBlockOptimized(input_nc, ngf, norm_layer, nonlinearity, use_spect, use_coord)
+        mult = 1
+        for i in range(self.layers - 1):
+            mult_prev = mult
+            mult = min(2 ** (i + 1), img_f // ngf)
+            block = EncoderBlock(ngf * mult_prev, ngf * mult, norm_layer, nonlinearity, use_spect, use_coord)
+            setattr(self, 'encoder' + str(i), block)
+
+        self.feature_block = FeatureAdaptBlock1(2048, ngf * mult, norm_layer, nonlinearity)
+
+        self.PCTM = PCTM(d_model=ngf * mult, nhead=nhead, num_CABs=num_CABs, num_TTBs=num_TTBs,
+                         dim_feedforward=ngf * mult, activation="LeakyReLU", affine=affine, norm=norm)
+
+        for i in range(self.layers):
+            mult_prev = mult
+            mult = min(2 ** (self.layers - i - 2), img_f // ngf) if i != self.layers - 1 else 1
+            up = ResBlockDecoder(ngf * mult_prev, ngf * mult, ngf * mult, norm_layer, nonlinearity, use_spect, use_coord)
+            setattr(self, 'decoder' + str(i), up)
+
+        self.outconv = Output(ngf, output_nc, 3, None, nonlinearity, use_spect, use_coord)
+
+    def tf(self, tape, reid_f, source_pose):
+        F_p = self.block0.tf(tape, source_pose)
+        skips = []
+        for i in range(self.layers - 1):
+            skips.append(F_p)
+            F_p = getattr(self, 'encoder' + str(i)).tf(tape, F_p)
+        F_id = self.feature_block.tf(tape, reid_f)
+        F_g = self.PCTM.tf(tape, F_p, F_id)
+        for i in range(self.layers):
+            extra = skips.pop() if i < self.layers - 1 else None
+            F_g = getattr(self, 'decoder' + str(i)).tf(tape, F_g, extra=extra)
+        return self.outconv.tf(tape, F_g)
+
+    def tb(self, tape, dy, need_dx=True):
+        d = self.outconv.tb(tape, dy)
+        dskips = []
+        for i in range(self.layers - 1, -1, -1):
+            out = getattr(self, 'decoder' + str(i)).tb(tape, d)
+            if isinstance(out, tuple):
+                d, ds = out
+                dskips.append(ds)            # gradient of the skip popped at decoder i (= skips[layers - 2 - i])
+            else:
+                d = out
+        d_fp, d_fid = self.PCTM.tb(tape, d)
+        need_f = tape.needs_input is None or bool(tape.needs_input[0])
+        d_reid = self.feature_block.tb(tape, d_fid, need_dx=need_f)
+        # dskips was filled from the last decoder backwards: dskips[j] belongs to skips[j] (skip j = input of encoder j)
+        for i in range(self.layers - 2, -1, -1):
+            d_fp = getattr(self, 'encoder' + str(i)).tb(tape, d_fp)
+            d_fp = ops.axpby(d_fp, dskips[i], 1.0, 1.0, out=d_fp)
+        need_p = tape.needs_input is not None and len(tape.needs_input) > 1 and bool(tape.needs_input[1])
+        d_pose = self.block0.tb(tape, d_fp, need_dx=need_p)
+        return d_reid, d_pose
+
+
+##############################################################################
+# Discriminator
+##############################################################################
+class ResDiscriminator(RGModule):
+    """ResNet discriminator with spectral norm on every conv (networks.py:917-955)."""
+
+    def __init__(self, input_nc=3, ndf=64, img_f=1024, layers=3, norm='none', activation='LeakyReLU', use_spect=True,
+                 use_coord=False):
+        super(ResDiscriminator, self).__init__()
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        self.nonlinearity = nonlinearity
+
+        self.block0 = ResBlockEncoderOptimized(input_nc, ndf, ndf, norm_layer, nonlinearity, use_spect, use_coord)
+        mult = 1
+        for i in range(layers - 1):
+            mult_prev = mult
+            mult = min(2 ** (i + 1), img_f // ndf)
+            block = ResBlockEncoder(ndf * mult_prev, ndf * mult, ndf * mult_prev, norm_layer, nonlinearity, use_spect, use_coord)
+            setattr(self, 'encoder' + str(i), block)
+        self.conv = SpectralNorm(rnn.Conv2d(ndf * mult, 1, 1))
+
+    def tf(self, tape, x):
+        act, slope = _slope(self.nonlinearity)
+        out = self.block0.tf(tape, x)
+        for i in range(self.layers - 1):
+            out = getattr(self, 'encoder' + str(i)).tf(tape, out)
+        a = ops.act_fwd(out, act, slope)
+        tape.push(a)
+        return self.conv.tf(tape, a)
+
+    def tb(self, tape, dy, need_dx=True):
+        act, slope = _slope(self.nonlinearity)
+        d = self.conv.tb(tape, dy)
+        a = tape.pop()
+        d = ops.act_bwd(d, a, act, slope)
+        for i in range(self.layers - 2, -1, -1):
+            d = getattr(self, 'encoder' + str(i)).tb(tape, d)
+        need = tape.needs_input is None or bool(tape.needs_input[0])
+        return self.block0.tb(tape, d, need_dx=need)

@@ -60,9 +60,10 @@ class Conv2d(RGModule, _KrscCache):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s" % (
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
 
-    def tf(self, tape, x, act=ACT_NONE, slope=0.0):
-        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, act=act, slope=slope,
-                           w_krsc=self._krsc())
+    def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
+        """y = act(conv(x) + bias + residual): bias, residual add and activation run in the MFMA epilogue."""
+        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, residual=residual, act=act,
+                           slope=slope, w_krsc=self._krsc())
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
@@ -104,10 +105,10 @@ class ConvTranspose2d(RGModule, _KrscCache):
         return ((H - 1) * self.stride[0] - 2 * self.padding[0] + self.kernel_size[0] + self.output_padding[0],
                 (W - 1) * self.stride[1] - 2 * self.padding[1] + self.kernel_size[1] + self.output_padding[1])
 
-    def tf(self, tape, x, act=ACT_NONE, slope=0.0):
+    def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         hw = self.out_hw(x.shape[2], x.shape[3])
         if (x.shape[2] == 1 and x.shape[3] == 1 and self.padding == (0, 0) and self.output_padding == (0, 0)
-                and self.bias is None and act == ACT_NONE):
+                and self.bias is None and act == ACT_NONE and residual is None):
             # a 1x1 input makes the transposed conv a plain GEMM x[N][K] . w[K][C*KH*KW] (the generator's
             # 2432 -> 512 (8,4) layer, FD/fdgan/networks.py:105-109): run it with 1x1 geometry so no
             # MFMA work is spent on taps that fall outside the single input pixel
@@ -115,8 +116,8 @@ class ConvTranspose2d(RGModule, _KrscCache):
             y = ops.conv2d_dgrad(x, self.weight.view(K, C * KH * KW, 1, 1), (1, 1), 1, 0).view(x.shape[0], C, KH, KW)
             tape.push((x, None, act, slope))
             return y
-        y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, act=act, slope=slope,
-                             w_krsc=self._krsc())
+        y = ops.conv2d_dgrad(x, self.weight, hw, self.stride, self.padding, shift=self.bias, residual=residual, act=act,
+                             slope=slope, w_krsc=self._krsc())
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
@@ -379,3 +380,107 @@ class InstanceNorm2d(RGModule):
                                     need_dx=True, need_dres=has_res)
         dx = dx.view(shape)
         return (dx, dres.view(shape)) if has_res else dx
+
+
+class InstanceNorm1d(InstanceNorm2d):
+    """[B, C, L] token maps (the PTM blocks, CC/dual_gan/models/PTM.py:176-181): the same kernels on a [B, C, L, 1] view."""
+
+    def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
+        y = super(InstanceNorm1d, self).tf(tape, x.unsqueeze(-1), None if residual is None else residual.unsqueeze(-1),
+                                           act, slope)
+        return y.squeeze(-1)
+
+    def tb(self, tape, dy, need_dx=True):
+        out = super(InstanceNorm1d, self).tb(tape, dy.unsqueeze(-1), need_dx)
+        if isinstance(out, tuple):
+            return tuple(o.squeeze(-1) for o in out)
+        return out.squeeze(-1)
+
+
+class AvgPool2d(RGModule):
+    """nn.AvgPool2d(kernel_size=k, stride=k) (the only form the dual_gan blocks use)."""
+
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super(AvgPool2d, self).__init__()
+        stride = kernel_size if stride is None else stride
+        if _pair(kernel_size) != _pair(stride) or _pair(kernel_size)[0] != _pair(kernel_size)[1] or _pair(padding) != (0, 0):
+            raise NotImplementedError("AvgPool2d: only square kernel == stride, padding 0")
+        self.kernel_size = _pair(kernel_size)[0]
+
+    def tf(self, tape, x):
+        tape.push(x.shape)
+        return ops.avgpool2d_fwd(x, self.kernel_size)
+
+    def tb(self, tape, dy, need_dx=True):
+        shape = tape.pop()
+        return ops.avgpool2d_bwd(dy, shape, self.kernel_size) if need_dx else None
+
+
+class ReflectionPad2d(RGModule):
+    def __init__(self, padding):
+        super(ReflectionPad2d, self).__init__()
+        self.padding = int(padding)
+
+    def tf(self, tape, x):
+        return ops.reflection_pad2d_fwd(x, self.padding)
+
+    def tb(self, tape, dy, need_dx=True):
+        return ops.reflection_pad2d_bwd(dy, self.padding) if need_dx else None
+
+
+class SNConv2d(RGModule):
+    """nn.Conv2d under torch.nn.utils.spectral_norm (CC/dual_gan/models/base_function.py:121-126): parameters
+    `weight_orig`, `bias`; buffers `weight_u`, `weight_v` (same names / shapes as the hook-based original, so its
+    checkpoints load).  Every training-mode forward runs one power iteration in place on u, v and convolves with
+    W / sigma (`rg_spectral_norm_fwd`); the backward maps the filter gradient through the division."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, eps=1e-12):
+        super(SNConv2d, self).__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.eps = eps
+        self.weight_orig = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        init.kaiming_uniform_(self.weight_orig, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight_orig)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+        h, w = out_channels, self.weight_orig.numel() // out_channels
+        self.register_buffer("weight_u", torch.nn.functional.normalize(torch.randn(h), dim=0, eps=eps))
+        self.register_buffer("weight_v", torch.nn.functional.normalize(torch.randn(w), dim=0, eps=eps))
+        self.weight = None          # W / sigma of the latest forward (plain tensor, as the hook leaves it)
+
+    @classmethod
+    def from_conv(cls, conv):
+        m = cls(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.bias is not None)
+        with torch.no_grad():
+            m.weight_orig.copy_(conv.weight)
+            if conv.bias is not None:
+                m.bias.copy_(conv.bias)
+        return m
+
+    def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
+        w_sn, sigma = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training, self.eps)
+        self.weight = w_sn
+        wk = ops.weights_to_krsc(w_sn) if (w_sn.shape[2] * w_sn.shape[3] > 1 and w_sn.shape[1] % 4 == 0) else None
+        y = ops.conv2d_fwd(x, w_sn, self.stride, self.padding, shift=self.bias, residual=residual, act=act, slope=slope,
+                           w_krsc=wk)
+        keep_uv = tape.record and tape.wants(self.weight_orig)
+        tape.push((x, y if act != ACT_NONE else None, act, slope, w_sn, wk, sigma,
+                   self.weight_u.clone() if keep_uv else None, self.weight_v.clone() if keep_uv else None))
+        return y
+
+    def tb(self, tape, dy, need_dx=True, residual=None):
+        x, y, act, slope, w_sn, wk, sigma, u, v = tape.pop()
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
+        if tape.wants(self.weight_orig):
+            dw_sn = ops.conv2d_wgrad(x, dy, w_sn.shape, self.stride, self.padding)
+            tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,
+                                                                  out=tape.grad_out(self.weight_orig)))
+        if tape.wants(self.bias):
+            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(dy, w_sn, x.shape[2:], self.stride, self.padding, residual=residual, w_krsc=wk)

@@ -1,0 +1,57 @@
+"""Seeded oracle-side construction of the dual_gan golden cases (shared by make_golden_dualgan.py, which also runs the
+reference on the same weights and inputs, and by the tests, which only have the fixtures)."""
+from __future__ import absolute_import
+
+import torch
+
+from oracle import ref_dualgan as D
+
+
+def _perturb(net, seed, scale=0.05):
+    """Orthogonal(0.02) init leaves every activation tiny; add seeded noise so norms, biases and affine terms matter."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.dim() > 1:
+                p.add_(torch.randn(p.shape, generator=g) * scale / max(1.0, (p[0].numel()) ** 0.5) * 4)
+            else:
+                p.add_(torch.randn(p.shape, generator=g) * scale)
+    return net
+
+
+def posegen1_case():
+    torch.manual_seed(70)
+    net = D.o_init_weights(D.OPoseGenerator1(ngf=64, pose_nc=18, img_f=256, layers=3, norm='instance'))
+    _perturb(net, 71)
+    net.train()
+    inp = D.synth_dualgan_inputs(2, 64, 32, seed=72)
+    g = torch.Generator().manual_seed(73)
+    feat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
+    return net, (feat, inp['Ps'])
+
+
+def pctm_case():
+    torch.manual_seed(80)
+    net = D.OPCTM(64, 2, 2, 2, 64)
+    _perturb(net, 81)
+    g = torch.Generator().manual_seed(82)
+    return net, (torch.randn(2, 64, 4, 3, generator=g), torch.randn(2, 64, 5, 2, generator=g))
+
+
+def resdisc_case():
+    torch.manual_seed(90)
+    net = D.o_init_weights(D.OResDiscriminator(3, 32, 128, 3, True))
+    _perturb(net, 91, 0.02)
+    net.train()
+    x = D.synth_dualgan_inputs(2, 64, 32, seed=92)['Xs']
+    return net, x
+
+
+def lsgan_case():
+    g = torch.Generator().manual_seed(95)
+    return torch.randn(3, 1, 16, 8, generator=g) * 2
+
+
+def bicubic_case():
+    g = torch.Generator().manual_seed(96)
+    return torch.rand(2, 3, 32, 16, generator=g)

@@ -1,0 +1,145 @@
+"""Generates tests/golden/reference_dualgan.npz by importing the REFERENCE's own dual_gan modules (build container only).
+
+Loaded by path from /root/reference/cluster-contrast-reid-main/dual_gan/models: base_function.py, PTM.py, networks.py,
+external_function.py.  networks.py / PTM.py use package-relative imports, so empty package objects `dual_gan` and
+`dual_gan.models` (with __path__ pointing INTO THE REFERENCE TREE) are registered; two imports of things that are not
+installed and are never called on this path get empty placeholder module objects: `torchvision(.models)`
+(external_function.py:3, used only by VGG19) and `clustercontrast.utils.data.diff_augs` (networks.py:8, used only by
+Resize_ReID; the real file needs torchvision).  Nothing of the reference is copied into the repository.
+
+For every fixture the oracle (oracle/ref_dualgan.py) is built with seeded weights, the SAME state_dict is loaded into the
+reference module, both run on the same inputs, the script asserts agreement and stores the REFERENCE outputs.
+`bicubic_normalize` has no importable reference (diff_augs needs torchvision): it is anchored on torch's own
+F.interpolate, which is what torchvision's tensor resize calls.
+
+Usage:  python tests/golden/make_golden_dualgan.py
+"""
+from __future__ import absolute_import, print_function
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from oracle import ref_dualgan as D  # noqa: E402
+from tests.golden import cases_dualgan as C  # noqa: E402
+from tests.golden.cases import sub  # noqa: E402
+
+CC = "/root/reference/cluster-contrast-reid-main"
+
+
+def check(a, b, what, tol=1e-5):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-12)
+    print("  %-34s max|oracle-ref| = %.3e (scale %.3e)" % (what, err, scale))
+    assert err <= tol * scale + 1e-9, what
+
+
+def import_reference():
+    for name in ("torchvision", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    for name in ("clustercontrast", "clustercontrast.utils", "clustercontrast.utils.data"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    shell = types.ModuleType("clustercontrast.utils.data.diff_augs")
+    shell.my_resize = shell.my_transform = shell.my_normalize = None
+    sys.modules["clustercontrast.utils.data.diff_augs"] = shell
+    pkg = types.ModuleType("dual_gan")
+    pkg.__path__ = [os.path.join(CC, "dual_gan")]
+    sys.modules["dual_gan"] = pkg
+    sub_pkg = types.ModuleType("dual_gan.models")
+    sub_pkg.__path__ = [os.path.join(CC, "dual_gan", "models")]
+    sys.modules["dual_gan.models"] = sub_pkg
+    net = importlib.import_module("dual_gan.models.networks")
+    ext = importlib.import_module("dual_gan.models.external_function")
+    ptm = importlib.import_module("dual_gan.models.PTM")
+    return net, ext, ptm
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_net, ref_ext, ref_ptm = import_reference()
+    out = {}
+
+    print("PCTM")
+    on, (q, v) = C.pctm_case()
+    rn = ref_ptm.PCTM(d_model=64, nhead=2, num_CABs=2, num_TTBs=2, dim_feedforward=64, activation="LeakyReLU",
+                      affine=True, norm='instance')
+    rn.load_state_dict(on.state_dict())
+    yo, yr = on(q, v), rn(q, v)
+    check(yo, yr, "pctm_fwd")
+    out["pctm_fwd"], out["pctm_fwd_stats"] = sub(yr)
+
+    print("PoseGenerator1")
+    on, (feat, pose) = C.posegen1_case()
+    rn = ref_net.PoseGenerator1(64, 18, 256, 3, 'instance', 'LeakyReLU', False, False, 3, True, 2, 2, 2)
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    feat_r = feat.clone().requires_grad_(True)
+    feat_o = feat.clone().requires_grad_(True)
+    yo, yr = on(feat_o, pose), rn(feat_r, pose)
+    check(yo, yr, "posegen1_fwd")
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(yr.shape, generator=g)
+    yo.backward(dy)
+    yr.backward(dy)
+    check(feat_o.grad, feat_r.grad, "posegen1_dfeat", 1e-4)
+    out["posegen1_fwd"], out["posegen1_fwd_stats"] = sub(yr)
+    out["posegen1_dfeat"], out["posegen1_dfeat_stats"] = sub(feat_r.grad)
+    gsel = ["block0.model.0.weight", "encoder1.model.5.weight", "feature_block.model.0.weight",
+            "PCTM.encoder.layers.0.self_attn.in_proj_weight", "PCTM.decoder.layers.1.multihead_attn.out_proj.weight",
+            "PCTM.decoder.layers.0.linear1.weight", "PCTM.decoder.norm.weight", "decoder0.model.0.weight",
+            "decoder2.shortcut.0.weight", "outconv.conv1.bias"]
+    pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+    for k in gsel:
+        check(po[k].grad, pr[k].grad, "posegen1 grad " + k, 2e-4)
+        out["posegen1_g_" + k], _ = sub(pr[k].grad)
+
+    print("ResDiscriminator (spectral norm)")
+    on, x = C.resdisc_case()
+    rn = ref_net.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    for it in range(2):                       # two training forwards: u, v advance one power iteration each
+        yo, yr = on(x), rn(x)
+        check(yo, yr, "resdisc_fwd%d" % it)
+        out["resdisc_fwd%d" % it] = yr.detach().flatten().numpy().astype(np.float64)
+    (yo ** 2).mean().backward()
+    (yr ** 2).mean().backward()
+    pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+    for k in ["block0.model.0.weight_orig", "encoder1.model.3.weight_orig", "encoder0.shortcut.1.weight_orig", "conv.weight_orig",
+              "conv.bias"]:
+        check(po[k].grad, pr[k].grad, "resdisc grad " + k, 1e-4)
+        out["resdisc_g_" + k], _ = sub(pr[k].grad)
+    out["resdisc_u_block0"] = dict(rn.named_buffers())["block0.model.0.weight_u"].numpy().astype(np.float64)
+
+    print("GANLoss lsgan")
+    pred = C.lsgan_case()
+    crit = ref_ext.GANLoss('lsgan')
+    vals = []
+    for real in (True, False):
+        check(D.o_lsgan(pred, real, True), crit(pred, real, True), "lsgan disc %s" % real)
+        check(D.o_lsgan(pred, real, False), crit(pred, real, False), "lsgan gen %s" % real)
+        vals += [crit(pred, real, True).item(), crit(pred, real, False).mean().item()]
+    out["lsgan"] = np.array(vals)
+
+    print("bicubic + normalize (torch anchor)")
+    x = C.bicubic_case()
+    y = D.o_my_transform(x, (64, 32))
+    out["bicubic_normalize"], out["bicubic_normalize_stats"] = sub(y)
+
+    path = os.path.join(HERE, "reference_dualgan.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""CPU: the dual_gan oracle (oracle/ref_dualgan.py) against the golden vectors recorded from the reference's own
+dual_gan modules by tests/golden/make_golden_dualgan.py.  No reference and no GPU needed."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_dualgan as D
+from tests.golden import cases_dualgan as C
+from tests.golden.cases import sub
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_dualgan.npz"))
+
+
+def _cmp(got, key, tol=2e-5):
+    ref = GOLD[key]
+    got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale, "%s: %.3e vs scale %.3e" % (key, err, scale)
+
+
+def test_pctm():
+    net, (q, v) = C.pctm_case()
+    s, st = sub(net(q, v))
+    _cmp(s, "pctm_fwd")
+    _cmp(st, "pctm_fwd_stats")
+
+
+def test_posegen1_forward_backward():
+    net, (feat, pose) = C.posegen1_case()
+    feat = feat.clone().requires_grad_(True)
+    y = net(feat, pose)
+    s, st = sub(y)
+    _cmp(s, "posegen1_fwd")
+    _cmp(st, "posegen1_fwd_stats")
+    g = torch.Generator().manual_seed(5)
+    y.backward(torch.randn(y.shape, generator=g))
+    s, st = sub(feat.grad)
+    _cmp(s, "posegen1_dfeat", 1e-4)
+    params = dict(net.named_parameters())
+    for key in GOLD.files:
+        if key.startswith("posegen1_g_"):
+            _cmp(sub(params[key[len("posegen1_g_"):]].grad)[0], key, 2e-4)
+
+
+def test_resdiscriminator_spectral_norm():
+    net, x = C.resdisc_case()
+    for it in range(2):
+        y = net(x)
+        _cmp(y.detach().flatten().numpy(), "resdisc_fwd%d" % it)
+    (y ** 2).mean().backward()
+    params = dict(net.named_parameters())
+    for key in GOLD.files:
+        if key.startswith("resdisc_g_"):
+            _cmp(sub(params[key[len("resdisc_g_"):]].grad)[0], key, 1e-4)
+    _cmp(dict(net.named_buffers())["block0.model.0.weight_u"].numpy(), "resdisc_u_block0")
+
+
+def test_lsgan_and_bicubic():
+    pred = C.lsgan_case()
+    vals = []
+    for real in (True, False):
+        vals += [D.o_lsgan(pred, real, True).item(), D.o_lsgan(pred, real, False).mean().item()]
+    _cmp(vals, "lsgan")
+    s, st = sub(D.o_my_transform(C.bicubic_case(), (64, 32)))
+    _cmp(s, "bicubic_normalize")
+    _cmp(st, "bicubic_normalize_stats")
