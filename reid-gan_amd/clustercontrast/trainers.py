@@ -190,8 +190,12 @@ class ClusterContrastWithGANTrainer(object):
         feature -> generator loss (D frozen) + confidence-weighted cluster-contrast loss -> D step -> one backward
         through G and the encoder -> both optimizers step."""
         gan = self.gan
-        f_out = _first(self._forward(reid_inputs))
-        gan.synthesize_p(f_out.detach())
+        out = self._forward(reid_inputs)
+        f_out = _first(out)
+        # train-mode encoders return (bn_x, normalize(feature map)) (CC/clustercontrast/models/resnet.py:107); the
+        # committed loop passes that tuple straight to `.detach()` (SURVEY §9.4).  The generator's input is the map.
+        f_gan = out[1] if isinstance(out, (tuple, list)) and len(out) > 1 and out[1] is not None else f_out
+        gan.synthesize_p(f_gan.detach())
         loss_G = gan.get_loss_G(need_cm=False)
         if conf_weight is not None:
             conf_mask = conf_weight[indexes]

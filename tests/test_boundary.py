@@ -82,3 +82,34 @@ def test_state_dict_layout_matches_reference_keys():
     assert "base_model.base.fc.weight" in e.state_dict()       # the unused fc stays in checkpoints
     with pytest.raises(KeyError):
         RM.create('resnet51')
+
+
+def test_dualgan_state_dict_keys_match_reference_layout():
+    """the oracle's keys ARE the reference's (make_golden_dualgan loads one into the other)"""
+    from dual_gan.models import networks as N
+    from tests.golden import cases_dualgan as C
+    og, _ = C.posegen1_case()
+    rg = N.PoseGenerator1(64, 18, 256, 3, 'instance', 'LeakyReLU', False, False, 3, True, 2, 2, 2)
+    assert list(rg.state_dict().keys()) == list(og.state_dict().keys())
+    od, _ = C.resdisc_case()
+    rd = N.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)
+    assert sorted(rd.state_dict().keys()) == sorted(od.state_dict().keys())
+    for k, v in od.state_dict().items():
+        assert rd.state_dict()[k].shape == v.shape, k
+
+
+def test_dualgan_api_errors():
+    """error behaviour of the dual_gan factories (CC/dual_gan/models/networks.py:14-33, base_function.py:38-63)"""
+    import argparse
+    from dual_gan.models import base_function as BF
+    from dual_gan.models import networks as N
+    from dual_gan.models.external_function import GANLoss
+    with pytest.raises(NotImplementedError):
+        BF.get_norm_layer('group')
+    with pytest.raises(NotImplementedError):
+        BF.get_nonlinearity_layer('Swish')
+    with pytest.raises(NotImplementedError):
+        GANLoss('nonsense')
+    with pytest.raises(TypeError):
+        N.define_G(argparse.Namespace(model_gen='nope', init_type='orthogonal'), 3, 18)
+    assert BF.get_norm_layer('none') is None

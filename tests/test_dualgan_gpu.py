@@ -21,20 +21,6 @@ def _load(rg_mod, o_mod, dev):
     return rg_mod.to(dev)
 
 
-def test_state_dict_keys_match_reference_layout():
-    """the oracle's keys ARE the reference's (make_golden_dualgan loads one into the other)"""
-    from dual_gan.models import networks as N
-    from tests.golden import cases_dualgan as C
-    og, _ = C.posegen1_case()
-    rg = N.PoseGenerator1(64, 18, 256, 3, 'instance', 'LeakyReLU', False, False, 3, True, 2, 2, 2)
-    assert list(rg.state_dict().keys()) == list(og.state_dict().keys())
-    od, _ = C.resdisc_case()
-    rd = N.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)
-    assert sorted(rd.state_dict().keys()) == sorted(od.state_dict().keys())
-    for k, v in od.state_dict().items():
-        assert rd.state_dict()[k].shape == v.shape, k
-
-
 def test_multihead_attention_public_api(dev):
     """rg_hip.attention.MultiheadAttention called like nn.MultiheadAttention ([L, B, E]) — self and cross attention."""
     from rg_hip.attention import MultiheadAttention
@@ -143,3 +129,117 @@ def test_resdiscriminator(dev):
     rg.eval()
     on.eval()
     _check(rg(xd.detach()), on(x), 1e-3, "resdisc eval fwd")
+
+
+def _gan_opt(**kw):
+    opt = dict(gan_train=True, checkpoints_dir="/tmp/rg_ckpt", name="t", load_pretrain="", model_gen="Pose", num_feats=256,
+               layers_g=3, image_nc=3, pose_nc=18, norm="instance", use_spect_g=False, use_spect_d=True, use_coord=False,
+               num_blocks=3, nhead=2, num_CABs=2, num_TTBs=2, dis_layers=3, init_type="orthogonal", verbose=False,
+               pool_size=0, gan_lr=2e-4, gan_mode="lsgan", no_vgg_loss=True, beta1=0.5, ratio_g2d=0.1, lambda_rec=2.0,
+               lambda_g=5.0, gan_lr_policy="lambda", iter_start=0, niter=100, niter_decay=100, continue_train=False,
+               which_epoch="latest", bipath_gan=False, use_adp=False)
+    opt.update(kw)
+    return argparse.Namespace(**opt)
+
+
+def _ae_pair(dev):
+    """AEModel (HIP) and OAEModel (oracle) on identical weights."""
+    from dual_gan.models.models import create_model
+    from oracle import ref_dualgan as D
+    from tests.golden import cases_dualgan as C
+    opt = _gan_opt(model="AE")
+    model = create_model(opt)
+    og, _ = C.posegen1_case()
+    od, _ = C.resdisc_case()
+    model.net_G.module.load_state_dict(og.state_dict())
+    model.net_D.module.load_state_dict(od.state_dict())
+    return model, D.OAEModel(og, od), D
+
+
+def _adam_close(rg_mod, o_mod, lr, steps, what):
+    """After `steps` Adam steps every parameter moved by <= ~lr per step on both sides; first-step updates are
+    sign-like, so compare against the step size, not the parameter scale."""
+    op = dict(o_mod.named_parameters())
+    far = tot = 0
+    worst = 0.0
+    for n, p in rg_mod.named_parameters():
+        d = (p.detach().cpu().double() - op[n].detach().double()).abs()
+        worst = max(worst, d.max().item())
+        far += (d > 0.5 * lr * steps).sum().item()
+        tot += d.numel()
+    assert worst <= 3.0 * lr * steps, "%s: a parameter differs by %.3e (> 3 lr steps)" % (what, worst)
+    assert far <= 0.02 * tot, "%s: %.2f%% of the parameters differ by more than half a step" % (what, 100.0 * far / tot)
+
+
+def test_aemodel_gan_step(dev):
+    """AEModel.synthesize_p + optimize_generated (D update, then G update) for two steps: losses within 1e-3 at step
+    0; parameters Adam-close; step-1 losses (after sign-like first Adam updates) within 1e-2."""
+    model, omodel, D = _ae_pair(dev)
+    g = torch.Generator().manual_seed(11)
+    for it in range(2):
+        inp = D.synth_dualgan_inputs(4, 64, 32, seed=20 + it)
+        feat = torch.nn.functional.normalize(torch.randn(4, 2048, 8, 4, generator=g).abs(), dim=1)
+        omodel.set_input(inp)
+        model.set_input(inp)
+        fo = omodel.synthesize_p(feat)
+        fr = model.synthesize_p(feat.to(dev))
+        _check(fr, fo, 1e-3 if it == 0 else 2e-2, "fake image step %d" % it)
+        omodel.optimize_generated()
+        model.optimize_generated()
+        errs = model.get_current_errors()
+        tol = 1e-3 if it == 0 else 1e-2
+        assert abs(errs["D"] - omodel.loss_D.item()) <= tol * abs(omodel.loss_D.item()), (it, errs, omodel.loss_D.item())
+        assert abs(errs["G"] - omodel.loss_G.item()) <= tol * abs(omodel.loss_G.item()), (it, errs, omodel.loss_G.item())
+        _adam_close(model.net_G.module, omodel.net_G, 2e-4, it + 1, "G params step %d" % it)
+        _adam_close(model.net_D.module, omodel.net_D, 2e-5, it + 1, "D params step %d" % it)
+    assert model.get_current_learning_rate() == (2e-4, 2e-5)
+    model.update_learning_rate()
+
+
+def test_joint_step_4a(dev):
+    """BASELINE config 4a — the joint ReID + GAN step as committed (trainers_b.py:617-774): ResNet-50 cluster-contrast
+    encoder (GeM) -> PoseGenerator1 from the detached feature map -> lsgan / L1 generator loss + cluster-contrast loss ->
+    D step -> one backward through G and the encoder -> both optimizers.  Step-0 losses are forward quantities (1e-3);
+    the memory bank and the G / D parameters after the step are checked Adam-aware."""
+    import torch.nn.functional as F
+    from oracle import ref_torch as O
+    import clustercontrast.models as M
+    from clustercontrast.models.cm import ClusterMemory
+    from clustercontrast.trainers import ClusterContrastWithGANTrainer
+    from rg_hip import optim as roptim
+    model, omodel, D = _ae_pair(dev)
+    torch.manual_seed(3)
+    oenc = O.OCCResNet(50, pooling_type="gem")
+    renc = M.create('resnet50', pretrained=False, pooling_type="gem")
+    renc.load_state_dict(oenc.state_dict())
+    renc.to(dev).train()
+    oenc.train()
+    K, Dm = 32, oenc.num_features
+    g = torch.Generator().manual_seed(6)
+    bank = F.normalize(torch.randn(K, Dm, generator=g), dim=1)
+    om = O.OClusterMemory(Dm, K, temp=0.05, momentum=0.1)
+    om.features = bank.clone()
+    rm = ClusterMemory(Dm, K, temp=0.05, momentum=0.1).to(dev)
+    rm.features = bank.clone().to(dev)
+    oopt = torch.optim.Adam([{"params": [p]} for p in oenc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    ropt = roptim.Adam([{"params": [p]} for p in renc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    trainer = ClusterContrastWithGANTrainer(renc, GAN=model, memory=rm)
+
+    B = 8
+    imgs = O.synth_images(B, 128, 64, seed=10)                 # encoder map 8x4 at 128x64
+    gan_in = D.synth_dualgan_inputs(B, 64, 32, seed=12)        # pose tokens 8x4 at 64x32
+    labels = torch.randint(0, K, (2,), generator=g).repeat_interleave(4)
+    indexes = torch.arange(B)
+    conf = torch.rand(64, generator=g) + 0.5
+
+    lo, lo_cl, lo_G, lo_D = D.o_joint_step(oenc, om, omodel, oopt, imgs, labels, gan_in, conf_mask=conf[indexes])
+    model.set_input(gan_in)
+    lr = trainer.joint_step(imgs.to(dev), labels.to(dev), indexes.to(dev), ropt, conf_weight=conf.to(dev))
+    errs = model.get_current_errors()
+    assert abs(lr.item() - lo.item()) <= 1e-3 * abs(lo.item()), (lr.item(), lo.item())
+    assert abs(errs["G"] - lo_G.item()) <= 1e-3 * abs(lo_G.item()), (errs, lo_G.item())
+    assert abs(errs["D"] - lo_D.item()) <= 1e-3 * abs(lo_D.item()), (errs, lo_D.item())
+    _check(model.fake_image, omodel.fake_image, 1e-3, "fake image")
+    _check_l2(rm.features, om.features, 1e-3, "bank after the step")
+    _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params")
+    _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params")
