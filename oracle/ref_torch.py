@@ -513,6 +513,58 @@ class OFDGANStep(object):
                                         ('D_i', loss_Di.item()), ('D_p', loss_Dp.item())]), fake.detach()
 
 
+def o_joint_step_fd(fd, encoder, memory, optimizer, imgs, labels, batch):
+    """BASELINE config 4b: the joint step of CC/clustercontrast/trainers_b.py:617-774 with the FD-GAN object (`fd`, an
+    OFDGANStep) in the GAN role.  Call order of the trainer: synthesize -> generator loss (discriminators as
+    constants) -> cluster-contrast loss -> discriminator gradients -> ONE backward of loss_cl + loss_G -> optimizer
+    steps; all four updates use gradients taken at the pre-update weights (the discriminator steps are applied after
+    the generator backward, which still needs their forward-pass weights)."""
+    origin, target, posemap, lab, noise = batch
+    f_out = encoder(imgs)
+    if isinstance(f_out, tuple):
+        f_out = f_out[0]
+    b2 = origin.shape[0]
+    f1, f2, id_score = fd.net_E(origin[:b2 // 2], origin[b2 // 2:])
+    a_id = torch.cat((f1, f2))
+    fake = fd.net_G(posemap, a_id.view(b2, -1, 1, 1), noise.view(b2, -1, 1, 1))
+    d_params = list(fd.net_Di.parameters()) + list(fd.net_Dp.parameters())
+    for p in d_params:
+        p.requires_grad = False
+    loss_v = F.cross_entropy(id_score, lab.view(-1))
+    loss_r = F.l1_loss(fake, target)
+    half = b2 // 2
+    fk1, fk2 = fake[:half], fake[half:]
+    mask = lab.view(-1, 1, 1, 1).expand_as(fk1) == 1
+    loss_sp = F.l1_loss(fk1[mask], fk2[mask])
+    _, _, pred_fake_Di = fd.net_Di(origin, fake)
+    pred_fake_Dp = fd.net_Dp(torch.cat((posemap, fake), dim=1))
+    g_di, g_dp = o_gan_loss(pred_fake_Di, True), o_gan_loss(pred_fake_Dp, True)
+    loss_G = g_di + g_dp + loss_r * fd.lam[0] + loss_v * fd.lam[1] + loss_sp * fd.lam[2]
+    loss_cl = memory(f_out, labels).mean()
+    loss = loss_cl + loss_G
+    for p in d_params:
+        p.requires_grad = True
+    fd.opt_Di.zero_grad()
+    fd.opt_Dp.zero_grad()
+    _, _, pred_real = fd.net_Di(origin, target)
+    _, _, pred_fake = fd.net_Di(origin, fake.detach())
+    loss_Di = (o_gan_loss(pred_real, True) + o_gan_loss(pred_fake, False)) * 0.5
+    loss_Di.backward()
+    pred_real = fd.net_Dp(torch.cat((posemap, target), dim=1))
+    pred_fake = fd.net_Dp(torch.cat((posemap, fake.detach()), dim=1))
+    loss_Dp = (o_gan_loss(pred_real, True) + o_gan_loss(pred_fake, False)) * 0.5
+    loss_Dp.backward()
+    fd.opt_G.zero_grad()
+    optimizer.zero_grad()
+    loss.backward()
+    fd.opt_G.step()
+    optimizer.step()
+    fd.opt_Di.step()
+    fd.opt_Dp.step()
+    return collections.OrderedDict([('loss', loss.item()), ('loss_cl', loss_cl.item()), ('G', loss_G.item()),
+                                    ('D_i', loss_Di.item()), ('D_p', loss_Dp.item())]), fake.detach()
+
+
 def o_cc_step(encoder, memory, optimizer, imgs, labels):
     """ClusterContrastTrainer.train body, CC/clustercontrast/trainers.py:229-249 (tuple output unpacked as in
     train_all :157)."""

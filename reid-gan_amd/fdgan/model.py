@@ -229,7 +229,9 @@ class FDGANModel(object):
         loss_D.backward()
         self.loss_Di = loss_D.detach()
 
-    def backward_G(self):
+    def build_loss_G(self):
+        """The generator objective of backward_G (:188-214) as an attached 0-dim device tensor (no backward yet);
+        the discriminators take part as constants."""
         loss_v = RF.cross_entropy(self.id_score, self.labels.view(-1))
         loss_r = RF.l1_loss(self.fake, self.target)
         half = self.fake.size(0) // 2
@@ -247,15 +249,17 @@ class FDGANModel(object):
                             (loss_r, self.opt.lambda_recon),
                             (loss_v, self.opt.lambda_veri),
                             (loss_sp, self.opt.lambda_sp)])
-        loss_G.backward()
-
-        del self.id_score
         self.loss_G = loss_G.detach()
         self.loss_v = loss_v.detach()
         self.loss_sp = loss_sp.detach()
         self.loss_r = loss_r.detach()
         self.loss_G_GAN_Di = loss_G_GAN_Di.detach()
         self.loss_G_GAN_Dp = loss_G_GAN_Dp.detach()
+        return loss_G
+
+    def backward_G(self):
+        self.build_loss_G().backward()
+        del self.id_score
         self.fake = self.fake.detach()
 
     def optimize_parameters(self):

@@ -428,3 +428,91 @@ def test_fdgan_step_matches_oracle(dev):
         else:
             assert far <= 0.10 * tot, "net_%s: %d of %d elements more than lr/10 apart" % (name, far, tot)
             assert sabs / tot <= 0.1 * lr_adam, "net_%s: mean |dp| %.3e" % (name, sabs / tot)
+
+
+def test_joint_step_4b_fdgan_adaptor(dev):
+    """BASELINE config 4b: the joint ReID + GAN trainer step with FDGANModel in the GAN role (fdgan.adaptor.FDGANAdaptor)
+    against oracle.o_joint_step_fd.  Step-0 losses are forward quantities (1e-3); the SGD discriminators' updates are
+    linear in the gradient (L2), the Adam nets are bounded by the step size."""
+    import torch.nn.functional as F
+    from oracle import ref_torch as O
+    from fdgan.model import FDGANModel
+    from fdgan.adaptor import FDGANAdaptor
+    import clustercontrast.models as M
+    from clustercontrast.models.cm import ClusterMemory
+    from clustercontrast.trainers import ClusterContrastWithGANTrainer
+    from rg_hip import optim as roptim
+    torch.manual_seed(23)
+    b = 2
+    oE = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True), O.OEltwiseSubEmbed(True, True, 2048, 2))
+    oDi = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True), O.OEltwiseSubEmbed(True, True, 2048, 1))
+    for net in (oE, oDi):
+        net.embed_model.classifier.weight.data.normal_(0, 0.05)
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                m.running_mean.normal_(0, 0.05)
+                m.running_var.uniform_(0.8, 1.2)
+                m.weight.data.uniform_(0.4, 0.6)
+    oG = O.OPoseGenerator(128, 2048, 256, dropout=0.0)
+    oG.apply(O.o_weights_init_normal)
+    oDp = O.OPatchDiscriminator(21)
+    oDp.apply(O.o_weights_init_normal)
+    model = FDGANModel(_opt())
+    model.net_E.module.load_state_dict(oE.state_dict())
+    model.net_G.module.load_state_dict(oG.state_dict())
+    model.net_Di.module.load_state_dict(oDi.state_dict())
+    model.net_Dp.module.load_state_dict(oDp.state_dict())
+    model.reset_model_status()
+    ofd = O.OFDGANStep(oE, oG, oDi, oDp, lr=0.001, stage=2, lambda_recon=100.0, lambda_veri=10.0, lambda_sp=10.0)
+    init_D = {n: {k: v.clone() for k, v in net.state_dict().items()} for n, net in (("Di", oDi), ("Dp", oDp))}
+
+    oenc = O.OCCResNet(50, pooling_type="gem")
+    renc = M.create('resnet50', pretrained=False, pooling_type="gem")
+    renc.load_state_dict(oenc.state_dict())
+    renc.to(dev).train()
+    oenc.train()
+    K, Dm = 32, oenc.num_features
+    g = torch.Generator().manual_seed(6)
+    bank = F.normalize(torch.randn(K, Dm, generator=g), dim=1)
+    om = O.OClusterMemory(Dm, K, temp=0.05, momentum=0.1)
+    om.features = bank.clone()
+    rm = ClusterMemory(Dm, K, temp=0.05, momentum=0.1).to(dev)
+    rm.features = bank.clone().to(dev)
+    oopt = torch.optim.Adam([{"params": [p]} for p in oenc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    ropt = roptim.Adam([{"params": [p]} for p in renc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    gan = FDGANAdaptor(model)
+    trainer = ClusterContrastWithGANTrainer(renc, GAN=gan, memory=rm)
+
+    imgs = O.synth_images(8, 128, 64, seed=10)
+    labels = torch.randint(0, K, (2,), generator=g).repeat_interleave(4)
+    batch = O.synth_fdgan_batch(b, seed=100)
+    origin, target, pose, lab, noise = batch
+    ref, ref_fake = O.o_joint_step_fd(ofd, oenc, om, oopt, imgs, labels, batch)
+    pid1 = torch.arange(b)
+    pid2 = torch.where(lab == 1, pid1, pid1 + 1000)
+    in1 = dict(pid=pid1, origin=origin[:b], target=target[:b], posemap=pose[:b], noise=noise[:b])
+    in2 = dict(pid=pid2, origin=origin[b:], target=target[b:], posemap=pose[b:])
+    gan.set_input((in1, in2))
+    loss = trainer.joint_step(imgs.to(dev), labels.to(dev), torch.arange(8).to(dev), ropt)
+    errs = gan.get_current_errors()
+    assert abs(loss.item() - ref['loss']) <= 1e-3 * abs(ref['loss']), (loss.item(), ref['loss'])
+    for k in ('G', 'D_i', 'D_p'):
+        assert abs(errs[k] - ref[k]) <= 1e-3 * max(abs(ref[k]), 1e-3), (k, errs[k], ref[k])
+    _check(gan.fake_image, ref_fake, 1e-3, "fake")
+    _check_l2(rm.features, om.features, 1e-3, "bank after the step")
+    for name, rn, on in (("Di", model.net_Di.module, oDi), ("Dp", model.net_Dp.module, oDp)):
+        num = den = 0.0
+        so, s0 = on.state_dict(), init_D[name]
+        for k, v in rn.state_dict().items():
+            if v.dtype != torch.float32 or "running" in k:
+                continue
+            a, r_ = v.detach().double().cpu(), so[k].double()
+            num += (a - r_).pow(2).sum().item()
+            den += (r_ - s0[k].double()).pow(2).sum().item()
+        assert den > 0 and (num / den) ** 0.5 <= 1e-2, (name, (num / max(den, 1e-300)) ** 0.5)
+    lr_adam = 1e-4
+    for rn, on in ((model.net_E.module, oE), (model.net_G.module, oG)):
+        so = on.state_dict()
+        for k, v in rn.state_dict().items():
+            if v.dtype == torch.float32 and "running" not in k:
+                assert (v.detach().double().cpu() - so[k].double()).abs().max().item() <= 3.0 * lr_adam, k
