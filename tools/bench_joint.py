@@ -2,6 +2,7 @@
 """Throughput of the other step configurations of BASELINE.json on one MI355X (bench.py stays on the headline config 2):
   cc      — config 3: cluster-contrast step, ResNet-50 (layer4 stride 1) + GeM, B crops of 256x128, K = 2048 clusters
   joint4a — config 4a: joint ReID + GAN step as committed (AEModel 'Pose' generator at 128x64 + spectral-norm D)
+  joint4b — config 4b: the same trainer step with FDGANModel in the GAN role (B crops = B/2 FD-GAN pairs)
 usage: python tools/bench_joint.py [cc|joint4a] [--batch 32] [--steps 10] [--warmup 3]
 Prints one JSON line per run (images/s, ms/step, per-family kernel time from the library's HIP-event profiler)."""
 from __future__ import absolute_import, print_function
@@ -22,7 +23,7 @@ import torch.nn.functional as F  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["cc", "joint4a"])
+    ap.add_argument("workload", choices=["cc", "joint4a", "joint4b"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -52,6 +53,21 @@ def main():
         def step():
             return trainer.step(imgs, labels, opt)
         gflop_per_crop = 24.34
+    elif args.workload == "joint4b":
+        sys.path.insert(0, REPO)
+        import bench as HB
+        from fdgan.model import FDGANModel
+        from fdgan.adaptor import FDGANAdaptor
+        model = FDGANModel(HB.fdgan_opt(batch_size=B // 2))
+        model.reset_model_status()
+        gan = FDGANAdaptor(model)
+        pair = HB.synth_inputs(B // 2, dev, seed=1234)
+        trainer = ClusterContrastWithGANTrainer(enc, GAN=gan, memory=mem)
+
+        def step():
+            gan.set_input(pair)
+            return trainer.joint_step(imgs, labels, indexes, opt)
+        gflop_per_crop = 160.0
     else:
         from dual_gan.models.models import create_model
         gopt = argparse.Namespace(
