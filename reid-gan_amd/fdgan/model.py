@@ -166,6 +166,15 @@ class FDGANModel(object):
             g_params = list(self.net_G.parameters())
             self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_params)
 
+    def _aux_stream(self):
+        """Second HIP stream for work that is independent of the main chain (RG_AUX_STREAM=0 disables it)."""
+        if os.environ.get("RG_AUX_STREAM", "1") == "0":
+            return None
+        s = getattr(self, "_aux", None)
+        if s is None:
+            s = self._aux = torch.cuda.Stream(device=self.device)
+        return s
+
     def set_input(self, input):
         input1, input2 = input
         labels = (input1['pid'] == input2['pid']).long()
@@ -239,11 +248,23 @@ class FDGANModel(object):
         fake_2 = self.fake[half:]
         loss_sp = RF.l1_loss(fake_1, fake_2, self.labels.view(-1))       # rows with label == 1 (:191-194)
 
+        aux = self._aux_stream()
         with no_param_grad(self.net_Di.module, self.net_Dp.module):
-            _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
-            pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
-        loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
-        loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
+            if aux is not None:
+                # D_pd's pass (and, through autograd's stream bookkeeping, its backward) runs next to D_id's
+                main = torch.cuda.current_stream()
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
+                    loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
+                _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
+                loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
+                main.wait_stream(aux)
+            else:
+                _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
+                pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
+                loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
+                loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
 
         loss_G = _weighted([(loss_G_GAN_Di, 1.0), (loss_G_GAN_Dp, 1.0),
                             (loss_r, self.opt.lambda_recon),
@@ -269,13 +290,24 @@ class FDGANModel(object):
         encoder's backward still runs (`_rg_after_backward`).  Results are those of the reference order."""
         self.forward()
 
+        aux = self._aux_stream()
         self.optimizer_Di.zero_grad()
-        self.backward_Di()
-        self.reducers[1].reduce_async()
-
         self.optimizer_Dp.zero_grad()
-        self.backward_Dp()
-        self.reducers[2].reduce_async()
+        if aux is not None:
+            # the two discriminator updates are independent: D_pd's runs on a second stream next to D_id's
+            main = torch.cuda.current_stream()
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                self.backward_Dp()
+            self.backward_Di()
+            self.reducers[1].reduce_async()
+            main.wait_stream(aux)
+            self.reducers[2].reduce_async()
+        else:
+            self.backward_Di()
+            self.reducers[1].reduce_async()
+            self.backward_Dp()
+            self.reducers[2].reduce_async()
 
         self.reducers[1].wait()
         self.optimizer_Di.step()

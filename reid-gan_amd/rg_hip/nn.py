@@ -73,7 +73,7 @@ class Conv2d(RGModule, _KrscCache):
             dy = ops.act_bwd(dy, y, act, slope)
         if tape.wants(self.weight):
             tape.add_grad(self.weight, ops.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding,
-                                                        out=tape.grad_out(self.weight)))
+                                                        out=tape.grad_out(self.weight), side=True))
         if tape.wants(self.bias):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
@@ -127,7 +127,7 @@ class ConvTranspose2d(RGModule, _KrscCache):
             dy = ops.act_bwd(dy, y, act, slope)
         if tape.wants(self.weight):
             tape.add_grad(self.weight, ops.conv2d_wgrad(dy, x, self.weight.shape, self.stride, self.padding,
-                                                        out=tape.grad_out(self.weight)))
+                                                        out=tape.grad_out(self.weight), side=True))
         if tape.wants(self.bias):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:

@@ -5,6 +5,8 @@ otherwise (there is deliberately no CPU path).
 """
 from __future__ import absolute_import
 
+import os
+
 import torch
 
 from .lib import lib
@@ -13,7 +15,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream on the current device (fast path: no Stream object is built)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _chk(t, name="tensor", dtype=torch.float32):
@@ -127,7 +130,78 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
     return dx
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None):
+# ---- weight gradients on a second stream ------------------------------------------------------------------------
+# Inside a network's backward program the filter gradient of a layer is a leaf: nothing downstream of it runs before
+# the optimizer.  It is therefore launched on a side stream (ordered after the producer of dy by an event) and runs
+# concurrently with the data-gradient chain on the main stream, filling the tail of each small grid.  The session is
+# opened / joined by rg_hip.tape._NetFn.backward; operands stay referenced until the join, so the caching allocator cannot
+# hand their memory to later main-stream kernels while the side stream still reads it.  RG_WGRAD_STREAM=0 disables it.
+_SIDE = {"on": os.environ.get("RG_WGRAD_STREAM", "1") != "0", "sessions": {}}
+
+
+class _SideSession(object):
+    """Side stream + in-flight operand references of ONE main stream (networks running concurrently on different
+    streams each get their own)."""
+    __slots__ = ("stream", "depth", "refs", "used")
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.depth, self.refs, self.used = 0, [], False
+
+
+def _side_session(create=True):
+    main = torch.cuda.current_stream()
+    key = (main.device.index, main.cuda_stream)
+    sess = _SIDE["sessions"].get(key)
+    if sess is None and create:
+        sess = _SideSession(main.device)
+        _SIDE["sessions"][key] = sess
+    return main, sess
+
+
+def side_enable(on):
+    _SIDE["on"] = bool(on)
+
+
+def side_begin():
+    if _SIDE["on"]:
+        _side_session()[1].depth += 1
+
+
+def side_sync():
+    """the current stream waits for everything its side stream was given so far (session stays open)"""
+    main, sess = _side_session(create=False)
+    if sess is not None and sess.used:
+        ev = torch.cuda.Event()
+        ev.record(sess.stream)
+        main.wait_event(ev)
+
+
+def side_join():
+    main, sess = _side_session(create=False)
+    if sess is None:
+        return
+    sess.depth = max(0, sess.depth - 1)
+    if sess.depth == 0 and sess.used:
+        side_sync()
+        sess.refs = []
+        sess.used = False
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False):
+    if side and _SIDE["on"]:
+        main, sess = _side_session(create=False)
+        if sess is not None and sess.depth > 0:
+            x, dy = _chk(x, "x"), _chk(dy, "dy")
+            dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            sess.stream.wait_event(ev)
+            with torch.cuda.stream(sess.stream):
+                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw)
+            sess.refs.append((x, dy, dw))
+            sess.used = True
+            return dw
     x, dy = _chk(x, "x"), _chk(dy, "dy")
     N, C, H, W = x.shape
     K, Cw, KH, KW = w_shape

@@ -57,6 +57,7 @@ class Tape(object):
                 g = ops.axpby(g, None, 1.0, 0.0, out=v)           # move into the arena
             self.grads[k] = g
         else:
+            ops.side_sync()      # `prev` / `g` may still be in flight on the side stream
             self.grads[k] = ops.axpby(prev, g, 1.0, 1.0, out=prev)
 
 
@@ -77,7 +78,11 @@ class _NetFn(torch.autograd.Function):
         if tape is None:
             raise RuntimeError("rg_hip: backward through a network a second time (the tape is freed after backward)")
         need = ctx.needs_input_grad[2:2 + n_in]
-        dxs = ctx.net.tb(tape, *dys, need_dx=any(need))
+        ops.side_begin()
+        try:
+            dxs = ctx.net.tb(tape, *dys, need_dx=any(need))
+        finally:
+            ops.side_join()          # weight gradients launched on the side stream are complete from here on
         if not isinstance(dxs, (tuple, list)):
             dxs = (dxs,)
         dxs = tuple(dxs) + (None,) * (n_in - len(dxs))
