@@ -131,6 +131,21 @@ int rg_bicubic_normalize_fwd(const float* x, float* y, int N, int C, int H, int 
 int rg_bicubic_normalize_bwd(const float* dy, float* dx, int N, int C, int H, int W, int OH, int OW, const float* stdv,
                              rg_stream_t stream);
 
+/* ---- conv + frozen-statistics BatchNorm fold (E / D_id of FD-GAN: set_bn_fix, FD/fdgan/networks.py:57-60 with
+ * trainable affine parameters, model.py:72-85).  Forward: rg_conv2d_fwd with scale/shift from rg_bn_fold — the
+ * pre-normalisation tensor is never written.  Backward without it:
+ *   g = dy * act'(y), sum_g = channel sums (dbeta)                     rg_act_bwd_sum (g may be NULL for act none)
+ *   G = rg_conv2d_wgrad(x, g);  dgamma = invstd * (sum_m W[k][m] G[k][m] - mean * sum_g);  G *= scale (in place -> dW)
+ *                                                                      rg_bn_fold_wgrad (dgamma may be NULL)
+ *   dx = rg_conv2d_dgrad(g, rows of W scaled by scale)                 rg_scale_rows */
+int rg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+               float* scale, float* shift, float* invstd, int C, rg_stream_t stream);
+int rg_act_bwd_sum(const float* dy, const float* y_act, float* g, float* sum_g, int N, int C, int HW, int act, float slope,
+                   void* workspace, size_t workspace_bytes, rg_stream_t stream);
+int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
+                     const float* sum_g, float* dgamma, int K, int M, rg_stream_t stream);
+int rg_scale_rows(const float* w, const float* scale, float* out, int K, int M, rg_stream_t stream);
+
 /* ---- dual_gan blocks (CC/dual_gan/models/base_function.py, PTM.py) ---------------------------- */
 /* nn.AvgPool2d(k, k) of the ResBlockEncoder shortcuts, base_function.py:372-420; P = H / k, Q = W / k */
 int rg_avgpool2d_fwd(const float* x, float* y, int N, int C, int H, int W, int k, rg_stream_t stream);

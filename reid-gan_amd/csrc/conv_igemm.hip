@@ -186,6 +186,67 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[T::TM][T::TN]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+template <typename T, int ACT>
+__device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
+                                                    int wm, int wn, int lane, int Ng, int PIX, const FastDiv& d_pix) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+    const rsrc_t ro = make_rsrc(p.y, p.y_bytes);
+    const rsrc_t rr = make_rsrc(p.ep.res ? (const void*)p.ep.res : (const void*)p.y, p.ep.res ? p.y_bytes : 0u);
+    const rsrc_t rsc = make_rsrc(p.ep.scale ? p.ep.scale : p.ep.shift, p.ep.scale ? (unsigned)p.M * 4u : 0u);
+    const rsrc_t rsh = make_rsrc(p.ep.shift ? p.ep.shift : p.ep.scale, p.ep.shift ? (unsigned)p.M * 4u : 0u);
+    const bool has_scale = p.ep.scale != nullptr, has_res = p.ep.res != nullptr;
+    const unsigned rstride = (unsigned)PIX * 4u;
+    unsigned ob[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int nn = n0 + wn * T::WTN + j * 32 + l32;
+        ob[j] = OOB;
+        if (nn < Ng) {
+            const int im = fdiv(nn, d_pix);
+            ob[j] = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+        }
+    }
+    constexpr int RB = 8;          // rows per batch: RB residual loads + 2*RB affine loads in flight, ~4*RB live VGPRs
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int rb = 0; rb < 16; rb += RB) {
+            float sc[RB], sh[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int r = rb + q;
+                const unsigned moff = (unsigned)(mrow0 + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u;
+                sc[q] = has_scale ? bload(rsc, moff) : 1.f;      // zero-sized resources return 0 for every lane
+                sh[q] = bload(rsh, moff);
+            }
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) {
+                unsigned off[RB];
+                float rv[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = rb + q;
+                    const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
+                    off[q] = (mrow0 + mo < p.M) ? ob[j] + (unsigned)mo * rstride : OOB;
+                }
+                if (has_res) {
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) rv[q] = bload(rr, off[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    float v = acc[i][j][rb + q] * sc[q] + sh[q];
+                    if (has_res) v += rv[q];
+                    if (ACT == RG_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
+                    if (ACT == RG_ACT_TANH) v = tanhf(v);
+                    bstore(ro, off[q], v);
+                }
+            }
+        }
+}
+
 // Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
 // With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] instead.  Buffer stores: one VALU add per
 // element, lanes outside the tensor carry OOB and are dropped by the hardware.
@@ -222,28 +283,14 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
         }
         return;
     }
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) {
-        const int nn = n0 + wn * T::WTN + j * 32 + l32;
-        if (nn >= Ng) continue;
-        const int im = fdiv(nn, d_pix);
-        const int pix = nn - im * PIX;
-        const int64_t obase = (int64_t)im * p.M * PIX + pix;
-#pragma unroll
-        for (int i = 0; i < T::TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (p.ep.scale) v *= p.ep.scale[m];
-                    if (p.ep.shift) v += p.ep.shift[m];
-                    const int64_t o = obase + (int64_t)m * PIX;
-                    if (p.ep.res) v += p.ep.res[o];
-                    p.y[o] = rg_apply_act(v, p.ep.act, p.ep.slope);
-                }
-            }
-        }
+    // fused epilogue: y = act(acc * scale[m] + shift[m] + res).  Branch-free like the plain path: per-row scale / shift
+    // are two broadcast loads per (i, r) shared by the TN column blocks, the residual is a buffer load at the store
+    // offset (OOB lanes read 0 and their stores are dropped), the activation is resolved by one uniform switch.
+    switch (p.ep.act) {
+        case RG_ACT_RELU: store_tile_epilogue<T, RG_ACT_RELU>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
+        case RG_ACT_LEAKY: store_tile_epilogue<T, RG_ACT_LEAKY>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
+        case RG_ACT_TANH: store_tile_epilogue<T, RG_ACT_TANH>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
+        default: store_tile_epilogue<T, RG_ACT_NONE>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
     }
 }
 

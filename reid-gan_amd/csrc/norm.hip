@@ -384,6 +384,99 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---- conv + frozen-statistics BatchNorm folded into the convolution ---------------------------------------------
+// y = act(conv(x, W) * scale + shift [+ residual]) runs in the conv epilogue (scale = gamma * invstd,
+// shift = beta - mean * scale), so the pre-normalisation tensor z is never written.  Backward without z:
+//   g      = dy * act'(y)                         (this kernel; + per-channel sum of g = dbeta)
+//   G      = wgrad(x, g)                          (conv kernel)        because sum_{n,p,q} g z = sum_{c,r,s} W G
+//   dgamma = invstd * (sum W.G - mean * sum g);  dW = scale * G        (bn_fold_wgrad_kernel, one workgroup per filter)
+//   dx     = dgrad(g, scale * W)                  (conv kernel on row-scaled filters, scale_rows_kernel)
+__global__ __launch_bounds__(256) void act_bwd_sum_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                          float* __restrict__ g_out, float* __restrict__ part, int N, int C,
+                                                          int HW, int L, int act, float slope, int want_sum) {
+    const int c = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+    const int64_t total = (int64_t)N * HW;
+    const int64_t beg = (int64_t)s * L;
+    int64_t end = beg + L;
+    if (end > total) end = total;
+    float s1 = 0.f;
+    if ((HW & 3) == 0) {
+        for (int64_t e = beg + (int64_t)threadIdx.x * 4; e < end; e += 256 * 4) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (act != RG_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(yact + o);
+                g.x *= act_grad_from_out(yv.x, act, slope);
+                g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope);
+                g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (g_out) *reinterpret_cast<float4*>(g_out + o) = g;
+            s1 += (g.x + g.y) + (g.z + g.w);
+        }
+    } else {
+        for (int64_t e = beg + threadIdx.x; e < end; e += 256) {
+            const int n = (int)(e / HW);
+            const int hw = (int)(e - (int64_t)n * HW);
+            const int64_t o = ((int64_t)n * C + c) * HW + hw;
+            float g = dy[o];
+            if (act != RG_ACT_NONE) g *= act_grad_from_out(yact[o], act, slope);
+            if (g_out) g_out[o] = g;
+            s1 += g;
+        }
+    }
+    if (!want_sum) return;
+    __shared__ float red[16];
+    s1 = rg_block_sum(s1, red);
+    if (threadIdx.x == 0) part[(int64_t)c * S + s] = s1;
+}
+
+__global__ void sum_slices_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(int64_t)c * S + s];
+    out[c] = a;
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                               float* __restrict__ invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = rsqrtf(var[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    invstd[c] = is;
+}
+
+__global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(const float* __restrict__ w, float* __restrict__ g,
+                                                            const float* __restrict__ scale, const float* __restrict__ invstd,
+                                                            const float* __restrict__ mean, const float* __restrict__ sum_g,
+                                                            float* __restrict__ dgamma, int M) {
+    __shared__ float red[16];
+    const int k = blockIdx.x;
+    const float* wr = w + (int64_t)k * M;
+    float* gr = g + (int64_t)k * M;
+    if (dgamma) {
+        float t = 0.f;
+        for (int m = threadIdx.x; m < M; m += 256) t += wr[m] * gr[m];
+        t = rg_block_sum(t, red);
+        if (threadIdx.x == 0) dgamma[k] = invstd[k] * (t - mean[k] * sum_g[k]);
+    }
+    const float sc = scale[k];
+    for (int m = threadIdx.x; m < M; m += 256) gr[m] *= sc;
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out, int M,
+                                  int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = w[i] * scale[i / M];
+}
+
 static int pick_slices(int N, int C, int HW, int* L) {
     const int64_t total = (int64_t)N * HW;
     int64_t S = rg::cdiv(2048, C);
@@ -507,4 +600,49 @@ extern "C" int rg_bn_eval_bwd(const float* x, const float* dy, const float* y_ac
         hipLaunchKernelGGL(bn_bwd_reduce_finalize_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, part, C, S, sum_dy,
                            sum_dy_xhat);
     return rg::check_launch("rg_bn_eval_bwd");
+}
+
+// ---- entry points of the conv + frozen-BatchNorm fold (see the kernel comments above) ------------------------
+extern "C" int rg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* scale, float* shift, float* invstd, int C, hipStream_t stream) {
+    RG_REQUIRE(running_mean && running_var && scale && shift && invstd && C > 0, "rg_bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(rg::cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, running_mean, running_var,
+                       eps, scale, shift, invstd, C);
+    return rg::check_launch("rg_bn_fold");
+}
+
+extern "C" int rg_act_bwd_sum(const float* dy, const float* y_act, float* g, float* sum_g, int N, int C, int HW, int act,
+                              float slope, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    RG_REQUIRE(dy && (g || sum_g) && N > 0 && C > 0 && HW > 0, "rg_act_bwd_sum: bad arguments");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_act_bwd_sum: the activation gradient needs the forward output");
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    if (sum_g && (!workspace || workspace_bytes < (size_t)C * S * sizeof(float))) {
+        rg::set_error("rg_act_bwd_sum: workspace too small");
+        return RG_ERR_WORKSPACE;
+    }
+    const double el = (double)N * C * HW;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * el * (1.0 + (act != RG_ACT_NONE ? 1.0 : 0.0) + (g ? 1.0 : 0.0)));
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(S, C), dim3(256), 0, stream, dy, y_act, g, part, N, C, HW, L, act, slope,
+                       sum_g ? 1 : 0);
+    if (sum_g) hipLaunchKernelGGL(sum_slices_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, part, C, S, sum_g);
+    return rg::check_launch("rg_act_bwd_sum");
+}
+
+extern "C" int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
+                                const float* sum_g, float* dgamma, int K, int M, hipStream_t stream) {
+    RG_REQUIRE(w && g && scale && K > 0 && M > 0, "rg_bn_fold_wgrad: bad arguments");
+    RG_REQUIRE(!dgamma || (invstd && running_mean && sum_g), "rg_bn_fold_wgrad: dgamma needs invstd, mean and sum_g");
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 12.0 * K * (double)M);
+    hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(K), dim3(256), 0, stream, w, g, scale, invstd, running_mean, sum_g, dgamma, M);
+    return rg::check_launch("rg_bn_fold_wgrad");
+}
+
+extern "C" int rg_scale_rows(const float* w, const float* scale, float* out, int K, int M, hipStream_t stream) {
+    RG_REQUIRE(w && scale && out && K > 0 && M > 0, "rg_scale_rows: bad arguments");
+    const int64_t total = (int64_t)K * M;
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, scale, out, M, total);
+    return rg::check_launch("rg_scale_rows");
 }

@@ -229,6 +229,86 @@ class _BatchNorm(RGModule):
         return (dx, dres) if has_res else dx
 
 
+# ---- convolution + BatchNorm as one layer ------------------------------------------------------------------------
+# With running statistics (FD-GAN's E and D_id: `set_bn_fix`, every eval-mode network) the normalisation is a per-channel
+# affine map of the conv output: it runs in the conv epilogue together with the residual add and the ReLU, and the
+# pre-normalisation tensor is never written or read again (see csrc/norm.hip, "conv + frozen-statistics BatchNorm").
+# Train-mode BatchNorm keeps the separate statistics / apply passes.
+class _Fold(object):
+    __slots__ = ("key", "scale", "shift", "invstd", "w_scaled", "w_scaled_krsc")
+
+
+def _fold_of(conv, bn):
+    w, g = conv.weight, bn.weight
+    aw, ag = getattr(w, "_rg_arena", None), getattr(g, "_rg_arena", None)
+    key = (aw.epoch if aw is not None else WEIGHT_EPOCH[0], ag.epoch if ag is not None else WEIGHT_EPOCH[0],
+           w._version, g._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, w.data_ptr())
+    f = getattr(conv, "_rg_fold", None)
+    if f is None or f.key != key:
+        f = _Fold()
+        f.key = key
+        f.scale, f.shift, f.invstd = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        f.w_scaled = f.w_scaled_krsc = None
+        conv._rg_fold = f
+    return f
+
+
+def conv_bn_tf(tape, conv, bn, x, residual=None, act=ACT_NONE):
+    """act(bn(conv(x)) [+ residual])"""
+    if bn.training or not bn.track_running_stats or not bn.affine or conv.bias is not None:
+        y = bn.tf(tape, conv.tf(tape, x), residual=residual, act=act)
+        tape.push(None)
+        return y
+    f = _fold_of(conv, bn)
+    y = ops.conv2d_fwd(x, conv.weight, conv.stride, conv.padding, scale=f.scale, shift=f.shift, residual=residual, act=act,
+                       w_krsc=conv._krsc())
+    tape.push((x, y if act != ACT_NONE else None, f, act, residual is not None))
+    return y
+
+
+def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None):
+    """-> dx, or (dx, d_residual) when the forward had a residual input; `residual` here is added to dx."""
+    rec = tape.pop()
+    if rec is None:
+        r = bn.tb(tape, dy)
+        d, dres = r if isinstance(r, tuple) else (r, None)
+        dx = conv.tb(tape, d, need_dx=need_dx, residual=residual)
+        return (dx, dres) if isinstance(r, tuple) else dx
+    x, y, f, act, has_res = rec
+    want_w, want_g, want_b = tape.wants(conv.weight), tape.wants(bn.weight), tape.wants(bn.bias)
+    need_sum = want_g or want_b
+    ob = tape.grad_out(bn.bias) if want_b else None
+    if act != ACT_NONE:
+        g, sg = ops.act_bwd_sum(dy, y, act, 0.0, need_g=True, need_sum=need_sum, out_sum=ob)
+    else:
+        g = dy
+        sg = ops.channel_sum(dy, out=ob) if need_sum else None
+    if want_b:
+        tape.add_grad(bn.bias, sg)
+    if want_w or want_g:
+        w = conv.weight.detach()
+        og = tape.grad_out(bn.weight) if want_g else None
+        dgamma = (og if og is not None else torch.empty_like(f.scale)) if want_g else None
+
+        def finish(G):
+            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma)
+        dw = ops.conv2d_wgrad(x, g, conv.weight.shape, conv.stride, conv.padding,
+                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=finish)
+        if want_w:
+            tape.add_grad(conv.weight, dw)
+        if want_g:
+            tape.add_grad(bn.weight, dgamma)
+    dx = None
+    if need_dx:
+        if f.w_scaled is None:
+            f.w_scaled = ops.scale_rows(conv.weight.detach(), f.scale)
+            ws = f.w_scaled
+            f.w_scaled_krsc = ops.weights_to_krsc(ws) if (ws.shape[2] * ws.shape[3] > 1 and ws.shape[1] % 4 == 0) else None
+        dx = ops.conv2d_dgrad(g, f.w_scaled, x.shape[2:], conv.stride, conv.padding, residual=residual,
+                              w_krsc=f.w_scaled_krsc)
+    return (dx, g) if has_res else dx
+
+
 class BatchNorm2d(_BatchNorm):
     pass
 

@@ -188,7 +188,9 @@ def side_join():
         sess.used = False
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False):
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
+    """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
+    behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
     if side and _SIDE["on"]:
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
@@ -198,8 +200,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False):
             ev.record(main)
             sess.stream.wait_event(ev)
             with torch.cuda.stream(sess.stream):
-                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw)
-            sess.refs.append((x, dy, dw))
+                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after)
+            sess.refs.append((x, dy, dw, after))         # the hook's closure keeps ITS operands alive too
             sess.used = True
             return dw
     x, dy = _chk(x, "x"), _chk(dy, "dy")
@@ -215,6 +217,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False):
     ws = workspace(nbytes, x.device)
     lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
                         _stream())
+    if after is not None:
+        after(dw)
     return dw
 
 
@@ -307,6 +311,44 @@ def bn_eval_bwd(x, dy, y_act, running_mean, running_var, gamma, eps=1e-5, act=AC
     lib.rg_bn_eval_bwd(_p(x), _p(dy), _p(y_act), _p(running_mean), _p(running_var), _p(gamma), _p(dx), _p(dres), _p(s1),
                        _p(s2), N, C, HW, eps, act, slope, _p(ws), ws.numel(), _stream())
     return dx, dres, s1, s2
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
+    """(scale, shift, invstd) of a frozen-statistics BatchNorm: y = z * scale + shift."""
+    C = running_mean.numel()
+    buf = torch.empty(3, C, dtype=torch.float32, device=running_mean.device)
+    lib.rg_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(buf[0]), _p(buf[1]), _p(buf[2]), C,
+                   _stream())
+    return buf[0], buf[1], buf[2]
+
+
+def act_bwd_sum(dy, y_act, act, slope=0.0, need_g=True, need_sum=True, out_sum=None):
+    """g = dy * act'(y) and its per-channel sums over N, HW -> (g, sum_g)."""
+    dy, y_act = _chk(dy, "dy"), _chk(y_act, "y")
+    N, C, HW = _nchw(dy)
+    g = torch.empty_like(dy) if need_g else None
+    sg = None
+    if need_sum:
+        sg = out_sum if out_sum is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+    ws = workspace(lib.rg_bn_workspace(N, C, HW), dy.device)
+    lib.rg_act_bwd_sum(_p(dy), _p(y_act), _p(g), _p(sg), N, C, HW, act, slope, _p(ws), ws.numel(), _stream())
+    return g, sg
+
+
+def bn_fold_wgrad(w, g, scale, invstd, running_mean, sum_g, dgamma=None):
+    """in place: g (= wgrad of the un-normalised output gradient) *= scale per filter; dgamma from sum(w * g)."""
+    K = w.shape[0]
+    M = w.numel() // K
+    lib.rg_bn_fold_wgrad(_p(w), _p(g), _p(scale), _p(invstd), _p(running_mean), _p(sum_g), _p(dgamma), K, M, _stream())
+    return g
+
+
+def scale_rows(w, scale):
+    w = _chk(w, "w")
+    out = torch.empty_like(w)
+    K = w.shape[0]
+    lib.rg_scale_rows(_p(w), _p(scale), _p(out), K, w.numel() // K, _stream())
+    return out
 
 
 def channel_sum(dy, out=None):

@@ -35,24 +35,21 @@ class Bottleneck(RGModule):
         self.stride = stride
 
     def tf(self, tape, x):
-        o = self.bn1.tf(tape, self.conv1.tf(tape, x), act=ACT_RELU)
-        o = self.bn2.tf(tape, self.conv2.tf(tape, o), act=ACT_RELU)
-        o = self.conv3.tf(tape, o)
+        o = rnn.conv_bn_tf(tape, self.conv1, self.bn1, x, act=ACT_RELU)
+        o = rnn.conv_bn_tf(tape, self.conv2, self.bn2, o, act=ACT_RELU)
         if self.downsample is not None:
-            idn = self.downsample[1].tf(tape, self.downsample[0].tf(tape, x))
+            idn = rnn.conv_bn_tf(tape, self.downsample[0], self.downsample[1], x)
         else:
             idn = x
-        return self.bn3.tf(tape, o, residual=idn, act=ACT_RELU)      # bn3 + add + relu in one pass
+        return rnn.conv_bn_tf(tape, self.conv3, self.bn3, o, residual=idn, act=ACT_RELU)   # conv3 + bn3 + add + relu
 
     def tb(self, tape, dy, need_dx=True):
-        d3, d_idn = self.bn3.tb(tape, dy)
+        d, d_idn = rnn.conv_bn_tb(tape, self.conv3, self.bn3, dy)
         if self.downsample is not None:
-            d_idn = self.downsample[0].tb(tape, self.downsample[1].tb(tape, d_idn), need_dx=need_dx)
-        d = self.conv3.tb(tape, d3)
-        d = self.conv2.tb(tape, self.bn2.tb(tape, d))
-        d = self.bn1.tb(tape, d)
+            d_idn = rnn.conv_bn_tb(tape, self.downsample[0], self.downsample[1], d_idn, need_dx=need_dx)
+        d = rnn.conv_bn_tb(tape, self.conv2, self.bn2, d)
         # the skip gradient is added in the dgrad epilogue of conv1 (no separate add kernel)
-        return self.conv1.tb(tape, d, need_dx=need_dx, residual=d_idn if need_dx else None)
+        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None)
 
 
 class BasicBlock(RGModule):
@@ -69,20 +66,18 @@ class BasicBlock(RGModule):
         self.stride = stride
 
     def tf(self, tape, x):
-        o = self.bn1.tf(tape, self.conv1.tf(tape, x), act=ACT_RELU)
-        o = self.conv2.tf(tape, o)
+        o = rnn.conv_bn_tf(tape, self.conv1, self.bn1, x, act=ACT_RELU)
         if self.downsample is not None:
-            idn = self.downsample[1].tf(tape, self.downsample[0].tf(tape, x))
+            idn = rnn.conv_bn_tf(tape, self.downsample[0], self.downsample[1], x)
         else:
             idn = x
-        return self.bn2.tf(tape, o, residual=idn, act=ACT_RELU)
+        return rnn.conv_bn_tf(tape, self.conv2, self.bn2, o, residual=idn, act=ACT_RELU)
 
     def tb(self, tape, dy, need_dx=True):
-        d2, d_idn = self.bn2.tb(tape, dy)
+        d, d_idn = rnn.conv_bn_tb(tape, self.conv2, self.bn2, dy)
         if self.downsample is not None:
-            d_idn = self.downsample[0].tb(tape, self.downsample[1].tb(tape, d_idn), need_dx=need_dx)
-        d = self.bn1.tb(tape, self.conv2.tb(tape, d2))
-        return self.conv1.tb(tape, d, need_dx=need_dx, residual=d_idn if need_dx else None)
+            d_idn = rnn.conv_bn_tb(tape, self.downsample[0], self.downsample[1], d_idn, need_dx=need_dx)
+        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None)
 
 
 _CFG = {
@@ -139,7 +134,7 @@ class TVResNet(RGModule):
 
 def trunk_tf(tape, mods, x):
     conv1, bn1, _relu, maxpool = mods[0], mods[1], mods[2], mods[3]
-    x = bn1.tf(tape, conv1.tf(tape, x), act=ACT_RELU)
+    x = rnn.conv_bn_tf(tape, conv1, bn1, x, act=ACT_RELU)
     x = maxpool.tf(tape, x)
     for layer in mods[4:]:
         x = layer.tf(tape, x)
@@ -151,8 +146,7 @@ def trunk_tb(tape, mods, dy, need_dx=True):
     for layer in reversed(mods[4:]):
         dy = layer.tb(tape, dy)
     dy = maxpool.tb(tape, dy)
-    dy = bn1.tb(tape, dy)
-    return conv1.tb(tape, dy, need_dx=need_dx)
+    return rnn.conv_bn_tb(tape, conv1, bn1, dy, need_dx=need_dx)
 
 
 def bn_all_eval(module):
