@@ -146,6 +146,14 @@ int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* 
                      const float* sum_g, float* dgamma, int K, int M, rg_stream_t stream);
 int rg_scale_rows(const float* w, const float* scale, float* out, int K, int M, rg_stream_t stream);
 
+/* All (conv, frozen BatchNorm) pairs of a network in ONE launch: `table` is a device array of 16 int64 words per pair
+ * {w, gamma, beta, running_mean, running_var, w_scaled, w_scaled_krsc|0, scale, shift, invstd, K, C, KH*KW,
+ *  eps (float bits), first workgroup of the pair, 0}; a pair takes ceil(K*C*KH*KW / rg_fold_chunk()) workgroups.
+ * Writes scale/shift/invstd and the filters times scale[k] in [K][C][RS] and (optionally) [K][RS][C] layout, so that the
+ * forward is conv(x, W*scale) + shift and the data gradient uses the same scaled filters. */
+int rg_fold_filters_multi(const void* table, int n_pairs, int total_blocks, rg_stream_t stream);
+int rg_fold_chunk(void);
+
 /* ---- dual_gan blocks (CC/dual_gan/models/base_function.py, PTM.py) ---------------------------- */
 /* nn.AvgPool2d(k, k) of the ResBlockEncoder shortcuts, base_function.py:372-420; P = H / k, Q = W / k */
 int rg_avgpool2d_fwd(const float* x, float* y, int N, int C, int H, int W, int k, rg_stream_t stream);

@@ -477,6 +477,57 @@ __global__ void scale_rows_kernel(const float* __restrict__ w, const float* __re
         out[i] = w[i] * scale[i / M];
 }
 
+// One launch folds EVERY (conv, frozen BatchNorm) pair of a network: per pair scale / shift / invstd and the filters
+// multiplied by scale[k] in the checkpoint layout [K][C][RS] and, when requested, in [K][RS][C] for the (r,s)-major
+// loaders.  The table lives in device memory, 16 int64 words per pair:
+//   0 w  1 gamma  2 beta  3 running_mean  4 running_var  5 w_scaled  6 w_scaled_krsc (0 = none)  7 scale  8 shift  9 invstd
+//   10 K  11 C  12 RS  13 eps (float bits)  14 first block of the pair  15 unused
+constexpr int FOLD_WORDS = 16;
+constexpr int FOLD_CHUNK = 2048;          // filter elements per workgroup
+
+__global__ __launch_bounds__(256) void fold_filters_multi_kernel(const long long* __restrict__ tab, int n_pairs) {
+    // binary search of the pair this block belongs to
+    int lo = 0, hi = n_pairs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[(int64_t)mid * FOLD_WORDS + 14] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = tab + (int64_t)lo * FOLD_WORDS;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    const float* gamma = reinterpret_cast<const float*>(e[1]);
+    const float* beta = reinterpret_cast<const float*>(e[2]);
+    const float* mean = reinterpret_cast<const float*>(e[3]);
+    const float* var = reinterpret_cast<const float*>(e[4]);
+    float* ws = reinterpret_cast<float*>(e[5]);
+    float* wk = reinterpret_cast<float*>(e[6]);
+    float* scale = reinterpret_cast<float*>(e[7]);
+    float* shift = reinterpret_cast<float*>(e[8]);
+    float* invstd = reinterpret_cast<float*>(e[9]);
+    const int K = (int)e[10], C = (int)e[11], RS = (int)e[12];
+    const float eps = __int_as_float((int)e[13]);
+    const int blk = (int)((long long)blockIdx.x - e[14]);
+    const int64_t total = (int64_t)K * C * RS;
+    const int64_t crs = (int64_t)C * RS;
+    const int64_t beg = (int64_t)blk * FOLD_CHUNK;
+    for (int64_t i = beg + threadIdx.x; i < beg + FOLD_CHUNK && i < total; i += 256) {
+        const int k = (int)(i / crs);
+        const int rem = (int)(i - (int64_t)k * crs);
+        const float is = rsqrtf(var[k] + eps);
+        const float sc = gamma[k] * is;
+        const float v = w[i] * sc;
+        ws[i] = v;
+        if (wk) {
+            const int c = rem / RS, rs = rem - c * RS;
+            wk[((int64_t)k * RS + rs) * C + c] = v;
+        }
+        if (rem == 0) {
+            scale[k] = sc;
+            shift[k] = beta[k] - mean[k] * sc;
+            invstd[k] = is;
+        }
+    }
+}
+
 static int pick_slices(int N, int C, int HW, int* L) {
     const int64_t total = (int64_t)N * HW;
     int64_t S = rg::cdiv(2048, C);
@@ -646,3 +697,13 @@ extern "C" int rg_scale_rows(const float* w, const float* scale, float* out, int
     hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, scale, out, M, total);
     return rg::check_launch("rg_scale_rows");
 }
+
+extern "C" int rg_fold_filters_multi(const void* table, int n_pairs, int total_blocks, hipStream_t stream) {
+    RG_REQUIRE(table && n_pairs > 0 && total_blocks > 0, "rg_fold_filters_multi: bad arguments");
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 12.0 * (double)total_blocks * FOLD_CHUNK);
+    hipLaunchKernelGGL(fold_filters_multi_kernel, dim3(total_blocks), dim3(256), 0, stream,
+                       static_cast<const long long*>(table), n_pairs);
+    return rg::check_launch("rg_fold_filters_multi");
+}
+
+extern "C" int rg_fold_chunk(void) { return FOLD_CHUNK; }

@@ -238,30 +238,117 @@ class _Fold(object):
     __slots__ = ("key", "scale", "shift", "invstd", "w_scaled", "w_scaled_krsc")
 
 
-def _fold_of(conv, bn):
+def _foldable(conv, bn):
+    return (isinstance(bn, _BatchNorm) and not bn.training and bn.track_running_stats and bn.affine and conv.bias is None
+            and isinstance(conv, Conv2d))
+
+
+def _pair_key(conv, bn):
     w, g = conv.weight, bn.weight
     aw, ag = getattr(w, "_rg_arena", None), getattr(g, "_rg_arena", None)
-    key = (aw.epoch if aw is not None else WEIGHT_EPOCH[0], ag.epoch if ag is not None else WEIGHT_EPOCH[0],
-           w._version, g._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, w.data_ptr())
+    return (aw.epoch if aw is not None else WEIGHT_EPOCH[0], ag.epoch if ag is not None else WEIGHT_EPOCH[0],
+            w._version, g._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, w.data_ptr(),
+            g.data_ptr())
+
+
+def _fold_of(conv, bn):
+    """Per-pair fold (one small launch group); networks fold all their pairs at once through FoldGroup."""
+    key = _pair_key(conv, bn)
     f = getattr(conv, "_rg_fold", None)
     if f is None or f.key != key:
         f = _Fold()
         f.key = key
         f.scale, f.shift, f.invstd = ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
-        f.w_scaled = f.w_scaled_krsc = None
+        ws = f.w_scaled = ops.scale_rows(conv.weight.detach(), f.scale)
+        f.w_scaled_krsc = ops.weights_to_krsc(ws) if (ws.shape[2] * ws.shape[3] > 1 and ws.shape[1] % 4 == 0) else None
         conv._rg_fold = f
     return f
 
 
+class FoldGroup(object):
+    """All (conv, BatchNorm) pairs of one network, folded by ONE kernel launch per weight version
+    (`rg_fold_filters_multi`): scale / shift / invstd and the scaled filters of every pair live in two flat buffers."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)
+        self.key = None
+        self.table = None
+
+    def _build(self, device):
+        chunk = lib_fold_chunk()
+        n_w = n_k = n_c = 0
+        for conv, bn in self.pairs:
+            w = conv.weight
+            n_w += (w.numel() + 63) // 64 * 64
+            if w.shape[2] * w.shape[3] > 1 and w.shape[1] % 4 == 0:
+                n_k += (w.numel() + 63) // 64 * 64
+            n_c += (w.shape[0] + 63) // 64 * 64
+        self.buf_w = torch.empty(n_w + n_k, dtype=torch.float32, device=device)
+        self.buf_c = torch.empty(3 * n_c, dtype=torch.float32, device=device)
+        rows, ow, oc, blocks = [], 0, 0, 0
+        self.folds = []
+        for conv, bn in self.pairs:
+            w = conv.weight
+            K, C, RS = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            f = _Fold()
+            f.w_scaled = self.buf_w[ow:ow + w.numel()].view(w.shape)
+            ow += (w.numel() + 63) // 64 * 64
+            if RS > 1 and C % 4 == 0:
+                f.w_scaled_krsc = self.buf_w[ow:ow + w.numel()].view(K, RS, C)
+                ow += (w.numel() + 63) // 64 * 64
+            else:
+                f.w_scaled_krsc = None
+            kc = (K + 63) // 64 * 64
+            f.scale, f.shift, f.invstd = (self.buf_c[oc:oc + K], self.buf_c[oc + kc:oc + kc + K],
+                                          self.buf_c[oc + 2 * kc:oc + 2 * kc + K])
+            oc += 3 * kc
+            eps_bits = int(torch.tensor(bn.eps, dtype=torch.float32).view(torch.int32).item())
+            rows.append([w.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                         bn.running_var.data_ptr(), f.w_scaled.data_ptr(),
+                         f.w_scaled_krsc.data_ptr() if f.w_scaled_krsc is not None else 0, f.scale.data_ptr(),
+                         f.shift.data_ptr(), f.invstd.data_ptr(), K, C, RS, eps_bits, blocks, 0])
+            blocks += (w.numel() + chunk - 1) // chunk
+            self.folds.append(f)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.blocks = blocks
+        self.ptrs = self._ptrs()
+
+    def _ptrs(self):
+        return tuple(conv.weight.data_ptr() for conv, _ in self.pairs) + tuple(bn.weight.data_ptr() for _, bn in self.pairs)
+
+    def usable(self):
+        return all(_foldable(conv, bn) for conv, bn in self.pairs)
+
+    def prepare(self):
+        """Fold every pair if any weight changed since the last call; afterwards conv._rg_fold is current."""
+        conv0, bn0 = self.pairs[0]
+        ptrs = self._ptrs()
+        if self.table is None or ptrs != self.ptrs:
+            self._build(conv0.weight.device)
+        key = tuple(_pair_key(conv, bn)[:7] for conv, bn in self.pairs)
+        if key == self.key:
+            return
+        ops.fold_filters_multi(self.table, len(self.pairs), self.blocks)
+        self.key = key
+        for (conv, bn), f in zip(self.pairs, self.folds):
+            f.key = _pair_key(conv, bn)
+            conv._rg_fold = f
+
+
+def lib_fold_chunk():
+    from .lib import lib
+    return lib.rg_fold_chunk()
+
+
 def conv_bn_tf(tape, conv, bn, x, residual=None, act=ACT_NONE):
     """act(bn(conv(x)) [+ residual])"""
-    if bn.training or not bn.track_running_stats or not bn.affine or conv.bias is not None:
+    if not _foldable(conv, bn):
         y = bn.tf(tape, conv.tf(tape, x), residual=residual, act=act)
         tape.push(None)
         return y
-    f = _fold_of(conv, bn)
-    y = ops.conv2d_fwd(x, conv.weight, conv.stride, conv.padding, scale=f.scale, shift=f.shift, residual=residual, act=act,
-                       w_krsc=conv._krsc())
+    f = _fold_of(conv, bn)               # a hit when the network's FoldGroup ran for this weight version
+    y = ops.conv2d_fwd(x, f.w_scaled, conv.stride, conv.padding, shift=f.shift, residual=residual, act=act,
+                       w_krsc=f.w_scaled_krsc)
     tape.push((x, y if act != ACT_NONE else None, f, act, residual is not None))
     return y
 
@@ -300,10 +387,6 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None):
             tape.add_grad(bn.weight, dgamma)
     dx = None
     if need_dx:
-        if f.w_scaled is None:
-            f.w_scaled = ops.scale_rows(conv.weight.detach(), f.scale)
-            ws = f.w_scaled
-            f.w_scaled_krsc = ops.weights_to_krsc(ws) if (ws.shape[2] * ws.shape[3] > 1 and ws.shape[1] % 4 == 0) else None
         dx = ops.conv2d_dgrad(g, f.w_scaled, x.shape[2:], conv.stride, conv.padding, residual=residual,
                               w_krsc=f.w_scaled_krsc)
     return (dx, g) if has_res else dx

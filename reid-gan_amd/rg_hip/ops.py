@@ -343,6 +343,10 @@ def bn_fold_wgrad(w, g, scale, invstd, running_mean, sum_g, dgamma=None):
     return g
 
 
+def fold_filters_multi(table, n_pairs, blocks):
+    lib.rg_fold_filters_multi(_p(table), n_pairs, blocks, _stream())
+
+
 def scale_rows(w, scale):
     w = _chk(w, "w")
     out = torch.empty_like(w)

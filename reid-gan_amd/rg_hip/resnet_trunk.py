@@ -132,8 +132,28 @@ class TVResNet(RGModule):
         return trunk_tb(tape, self.trunk_modules(), dy, need_dx)
 
 
+def _conv_bn_pairs(mods):
+    pairs = [(mods[0], mods[1])]
+    for layer in mods[4:]:
+        for blk in layer:
+            pairs.append((blk.conv1, blk.bn1))
+            pairs.append((blk.conv2, blk.bn2))
+            if hasattr(blk, "conv3"):
+                pairs.append((blk.conv3, blk.bn3))
+            if blk.downsample is not None:
+                pairs.append((blk.downsample[0], blk.downsample[1]))
+    return pairs
+
+
 def trunk_tf(tape, mods, x):
     conv1, bn1, _relu, maxpool = mods[0], mods[1], mods[2], mods[3]
+    if not bn1.training:
+        # frozen statistics: fold every BatchNorm of the trunk into its convolution with one launch per weight version
+        grp = getattr(conv1, "_rg_fold_group", None)
+        if grp is None:
+            grp = conv1._rg_fold_group = rnn.FoldGroup(_conv_bn_pairs(mods))
+        if grp.usable():
+            grp.prepare()
     x = rnn.conv_bn_tf(tape, conv1, bn1, x, act=ACT_RELU)
     x = maxpool.tf(tape, x)
     for layer in mods[4:]:
