@@ -69,10 +69,13 @@ int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y,
                   const float* residual, int act, float slope, void* workspace, size_t workspace_bytes,
                   rg_stream_t stream);
 size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW);
+/* relu_mask (dgrad only, may be NULL): a tensor shaped like dx; after scale/shift/residual/act the result is zeroed where
+ * relu_mask <= 0.  Passing the convolution's own forward INPUT (the ReLU output of the layer below) makes this the
+ * ReLU backward of that layer, applied to the sum of this data gradient and `residual` (the skip gradient). */
 int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K,
                     int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
-                    const float* shift, const float* residual, int act, float slope, void* workspace,
-                    size_t workspace_bytes, rg_stream_t stream);
+                    const float* shift, const float* residual, int act, float slope, const float* relu_mask,
+                    void* workspace, size_t workspace_bytes, rg_stream_t stream);
 int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, rg_stream_t stream);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,

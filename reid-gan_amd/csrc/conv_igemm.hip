@@ -72,6 +72,8 @@ struct Epilogue {
     const float* res;    // same shape as the output or nullptr
     int act;
     float slope;
+    const float* mask;   // same shape as the output or nullptr: after the residual add, v = mask > 0 ? v : 0 (the ReLU
+                         // backward of the layer that produced this conv's input, whose output IS that input)
 };
 
 struct ConvP {
@@ -186,28 +188,20 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[T::TM][T::TN]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+// Fused epilogue y = mask(act(acc * scale[m] + shift[m] + res)) for a tile whose column j of the wave starts at byte
+// offset ob[j] (OOB when outside) and whose GEMM rows are `rstride` bytes apart.  Branch-free: per-row scale / shift
+// are broadcast buffer loads shared by the TN column blocks, residual / mask are buffer loads at the store offset
+// issued RB at a time before their first use (OOB lanes read 0 and their stores are dropped by the hardware).
 template <typename T, int ACT>
-__device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
-                                                    int wm, int wn, int lane, int Ng, int PIX, const FastDiv& d_pix) {
-    const int l32 = lane & 31, kh = lane >> 5;
-    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+__device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], const unsigned (&ob)[T::TN],
+                                                    unsigned rstride, int mrow0) {
     const rsrc_t ro = make_rsrc(p.y, p.y_bytes);
     const rsrc_t rr = make_rsrc(p.ep.res ? (const void*)p.ep.res : (const void*)p.y, p.ep.res ? p.y_bytes : 0u);
+    const rsrc_t rm = make_rsrc(p.ep.mask ? (const void*)p.ep.mask : (const void*)p.y, p.ep.mask ? p.y_bytes : 0u);
     const rsrc_t rsc = make_rsrc(p.ep.scale ? p.ep.scale : p.ep.shift, p.ep.scale ? (unsigned)p.M * 4u : 0u);
     const rsrc_t rsh = make_rsrc(p.ep.shift ? p.ep.shift : p.ep.scale, p.ep.shift ? (unsigned)p.M * 4u : 0u);
-    const bool has_scale = p.ep.scale != nullptr, has_res = p.ep.res != nullptr;
-    const unsigned rstride = (unsigned)PIX * 4u;
-    unsigned ob[T::TN];
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) {
-        const int nn = n0 + wn * T::WTN + j * 32 + l32;
-        ob[j] = OOB;
-        if (nn < Ng) {
-            const int im = fdiv(nn, d_pix);
-            ob[j] = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
-        }
-    }
-    constexpr int RB = 8;          // rows per batch: RB residual loads + 2*RB affine loads in flight, ~4*RB live VGPRs
+    const bool has_scale = p.ep.scale != nullptr, has_res = p.ep.res != nullptr, has_mask = p.ep.mask != nullptr;
+    constexpr int RB = 8;          // rows per batch: bounds the live VGPRs of the epilogue
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -222,29 +216,55 @@ __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx
             }
 #pragma unroll
             for (int j = 0; j < T::TN; ++j) {
-                unsigned off[RB];
-                float rv[RB];
-#pragma unroll
-                for (int q = 0; q < RB; ++q) {
+                // offsets are recomputed at each use (one mad + select) rather than kept live across the loads
+                auto off_of = [&](int q) -> unsigned {
                     const int r = rb + q;
                     const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
-                    off[q] = (mrow0 + mo < p.M) ? ob[j] + (unsigned)mo * rstride : OOB;
-                }
+                    return (mrow0 + mo < p.M) ? ob[j] + (unsigned)mo * rstride : OOB;
+                };
+                float rv[RB];
                 if (has_res) {
 #pragma unroll
-                    for (int q = 0; q < RB; ++q) rv[q] = bload(rr, off[q]);
+                    for (int q = 0; q < RB; ++q) rv[q] = bload(rr, off_of(q));
                 }
+                if (has_mask) {                      // mask folded into the residual registers: sign carries it
+                    float mv[RB];
 #pragma unroll
-                for (int q = 0; q < RB; ++q) {
-                    float v = acc[i][j][rb + q] * sc[q] + sh[q];
-                    if (has_res) v += rv[q];
-                    if (ACT == RG_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
-                    if (ACT == RG_ACT_TANH) v = tanhf(v);
-                    bstore(ro, off[q], v);
+                    for (int q = 0; q < RB; ++q) mv[q] = bload(rm, off_of(q));
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        float v = acc[i][j][rb + q] * sc[q] + sh[q];
+                        if (has_res) v += rv[q];
+                        if (ACT == RG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
+                        if (ACT == RG_ACT_TANH) v = tanhf(v);
+                        bstore(ro, off_of(q), mv[q] > 0.f ? v : 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        float v = acc[i][j][rb + q] * sc[q] + sh[q];
+                        if (has_res) v += rv[q];
+                        if (ACT == RG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
+                        if (ACT == RG_ACT_TANH) v = tanhf(v);
+                        bstore(ro, off_of(q), v);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads from being hoisted (VGPR pressure)
             }
         }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_tile_epilogue_any(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN],
+                                                        const unsigned (&ob)[T::TN], unsigned rstride, int mrow0) {
+    switch (p.ep.act) {      // uniform
+        case RG_ACT_RELU: store_tile_epilogue<T, RG_ACT_RELU>(p, acc, ob, rstride, mrow0); break;
+        case RG_ACT_LEAKY: store_tile_epilogue<T, RG_ACT_LEAKY>(p, acc, ob, rstride, mrow0); break;
+        case RG_ACT_TANH: store_tile_epilogue<T, RG_ACT_TANH>(p, acc, ob, rstride, mrow0); break;
+        default: store_tile_epilogue<T, RG_ACT_NONE>(p, acc, ob, rstride, mrow0); break;
+    }
 }
 
 // Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
@@ -256,7 +276,7 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
                                                 int split) {
     const int l32 = lane & 31, kh = lane >> 5;
     const int mrow0 = m0 + wm * T::WTM + 4 * kh;
-    const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && p.ep.act == RG_ACT_NONE;
+    const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && !p.ep.mask && p.ep.act == RG_ACT_NONE;
     if (p.partial || plain) {
         const rsrc_t ro = p.partial ? make_rsrc(p.partial, p.partial_bytes) : make_rsrc(p.y, p.y_bytes);
         const unsigned rstride = (p.partial ? (unsigned)Ng : (unsigned)PIX) * 4u;    // bytes between GEMM rows
@@ -283,15 +303,17 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
         }
         return;
     }
-    // fused epilogue: y = act(acc * scale[m] + shift[m] + res).  Branch-free like the plain path: per-row scale / shift
-    // are two broadcast loads per (i, r) shared by the TN column blocks, the residual is a buffer load at the store
-    // offset (OOB lanes read 0 and their stores are dropped), the activation is resolved by one uniform switch.
-    switch (p.ep.act) {
-        case RG_ACT_RELU: store_tile_epilogue<T, RG_ACT_RELU>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
-        case RG_ACT_LEAKY: store_tile_epilogue<T, RG_ACT_LEAKY>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
-        case RG_ACT_TANH: store_tile_epilogue<T, RG_ACT_TANH>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
-        default: store_tile_epilogue<T, RG_ACT_NONE>(p, acc, m0, n0, wm, wn, lane, Ng, PIX, d_pix); break;
+    unsigned ob[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int nn = n0 + wn * T::WTN + j * 32 + l32;
+        ob[j] = OOB;
+        if (nn < Ng) {
+            const int im = fdiv(nn, d_pix);
+            ob[j] = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+        }
     }
+    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)PIX * 4u, mrow0);
 }
 
 // A operand loader shared by fwd (weights [M][Kg], k contiguous): float4 along k (AVEC) or scalar.
@@ -318,7 +340,7 @@ struct ALoadK {
 //           BMODE 2: 1x1 / stride 1 / pad 0 with H*W % 4 == 0: pixel operand as float4
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC>
-__global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_fwd_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(const ConvP p) {
 // MODE 2: MODE 1 layout + 1x1 / stride 1 / pad 0 with P*Q % 4 == 0: dy loads as float4 too (any K)
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_dgrad_kernel(const DgradP dp) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
@@ -668,34 +690,25 @@ __global__ __launch_bounds__(NT) void conv_dgrad_kernel(const DgradP dp) {
         store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split);
         return;
     }
+    // strided classes: pixel (hc, wc) of the class lands on (ah + SH*hc, aw + SW*wc); same fused epilogue
     const int l32 = lane & 31, kh = lane >> 5;
     const int HW = p.H * p.W;
+    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+    unsigned ob[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int nn = n0 + wn * T::WTN + j * 32 + l32;
-        if (nn >= cl.Ngc) continue;
-        const int im = fdiv(nn, cl.d_hw);
-        const int rem = nn - im * cl.Hc * cl.Wc;
-        const int hc = fdiv(rem, cl.d_w);
-        const int wc = rem - hc * cl.Wc;
-        const int h = ah + p.SH * hc, w = aw + p.SW * wc;
-        const int64_t obase = (int64_t)im * p.C * HW + h * p.W + w;
-#pragma unroll
-        for (int i = 0; i < T::TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * T::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < p.M) {
-                    float v = acc[i][j][r];
-                    if (p.ep.scale) v *= p.ep.scale[m];
-                    if (p.ep.shift) v += p.ep.shift[m];
-                    const int64_t o = obase + (int64_t)m * HW;
-                    if (p.ep.res) v += p.ep.res[o];
-                    p.y[o] = rg_apply_act(v, p.ep.act, p.ep.slope);
-                }
-            }
+        ob[j] = OOB;
+        if (nn < cl.Ngc) {
+            const int im = fdiv(nn, cl.d_hw);
+            const int rem = nn - im * cl.Hc * cl.Wc;
+            const int hc = fdiv(rem, cl.d_w);
+            const int wc = rem - hc * cl.Wc;
+            const int h = ah + p.SH * hc, w = aw + p.SW * wc;
+            ob[j] = (unsigned)((((int64_t)im * p.C + mrow0) * HW + h * p.W + w) * 4);
         }
     }
+    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)HW * 4u, mrow0);
 }
 
 // Data gradient for layers with <= 4 input channels (the RGB stem, FD/reid/models/resnet.py via torchvision conv1;
@@ -757,7 +770,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_smallc_kernel(const DgradP dp)
             if (p.ep.shift) v += p.ep.shift[c];
             const int64_t o = ((int64_t)img * p.C + c) * HW + h * p.W + w;
             if (p.ep.res) v += p.ep.res[o];
-            p.y[o] = rg_apply_act(v, p.ep.act, p.ep.slope);
+            v = rg_apply_act(v, p.ep.act, p.ep.slope);
+            if (p.ep.mask && !(p.ep.mask[o] > 0.f)) v = 0.f;
+            p.y[o] = v;
         }
     }
 }
@@ -778,7 +793,9 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
         if (ep.scale) v *= ep.scale[m];
         if (ep.shift) v += ep.shift[m];
         if (ep.res) v += ep.res[o];
-        out[o] = rg_apply_act(v, ep.act, ep.slope);
+        v = rg_apply_act(v, ep.act, ep.slope);
+        if (ep.mask && !(ep.mask[o] > 0.f)) v = 0.f;
+        out[o] = v;
     }
 }
 
@@ -1183,7 +1200,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     ConvP p;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = x; p.w = w; p.y = y;
-    p.ep = Epilogue{scale, shift, residual, act, slope};
+    p.ep = Epilogue{scale, shift, residual, act, slope, nullptr};
     p.M = K; p.Ng = N * P * Q; p.Kg = C * KH * KW;
     p.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
     p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
@@ -1229,7 +1246,7 @@ extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, i
 extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H,
                                int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
                                const float* scale, const float* shift, const float* residual, int act, float slope,
-                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                               const float* relu_mask, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_dgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(dy && w && dx, "rg_conv2d_dgrad: null tensor");
     RG_REQUIRE(SH <= 2 && SW <= 2, "rg_conv2d_dgrad: stride > 2 not supported (got %d,%d)", SH, SW);
@@ -1237,7 +1254,7 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
     ConvP& p = dp.c;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = dy; p.w = w; p.y = dx;
-    p.ep = Epilogue{scale, shift, residual, act, slope};
+    p.ep = Epilogue{scale, shift, residual, act, slope, relu_mask};
     p.M = C;
     p.x_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
     p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
@@ -1362,7 +1379,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     ConvP p;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = x; p.w = dy;
-    p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f};
+    p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f, nullptr};
     p.M = K; p.Ng = C * KH * KW; p.Kg = N * P * Q;
     const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
     p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;

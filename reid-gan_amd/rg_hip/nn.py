@@ -67,7 +67,9 @@ class Conv2d(RGModule, _KrscCache):
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
-    def tb(self, tape, dy, need_dx=True, residual=None):
+    def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False):
+        """mask_input: the conv's input x is the ReLU output of the layer below — its backward (zero where x <= 0) is
+        applied to dx (+ residual) in the dgrad epilogue."""
         x, y, act, slope = tape.pop()
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
@@ -79,7 +81,7 @@ class Conv2d(RGModule, _KrscCache):
         if not need_dx:
             return None
         return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual,
-                                w_krsc=self._krsc())
+                                w_krsc=self._krsc(), relu_mask=x if mask_input else None)
 
 
 class ConvTranspose2d(RGModule, _KrscCache):
@@ -353,23 +355,25 @@ def conv_bn_tf(tape, conv, bn, x, residual=None, act=ACT_NONE):
     return y
 
 
-def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None):
-    """-> dx, or (dx, d_residual) when the forward had a residual input; `residual` here is added to dx."""
+def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False, mask_input=False):
+    """-> dx, or (dx, d_residual) when the forward had a residual input; `residual` here is added to dx.
+    dy_masked: dy already carries this layer's ReLU backward (the consumer's dgrad applied it, see mask_input);
+    mask_input: apply the ReLU backward of the layer BELOW (whose output is this conv's input) to dx + residual."""
     rec = tape.pop()
     if rec is None:
-        r = bn.tb(tape, dy)
+        r = bn.tb(tape, dy)                   # re-applying the mask to an already masked dy is a no-op
         d, dres = r if isinstance(r, tuple) else (r, None)
-        dx = conv.tb(tape, d, need_dx=need_dx, residual=residual)
+        dx = conv.tb(tape, d, need_dx=need_dx, residual=residual, mask_input=mask_input)
         return (dx, dres) if isinstance(r, tuple) else dx
     x, y, f, act, has_res = rec
     want_w, want_g, want_b = tape.wants(conv.weight), tape.wants(bn.weight), tape.wants(bn.bias)
     need_sum = want_g or want_b
     ob = tape.grad_out(bn.bias) if want_b else None
-    if act != ACT_NONE:
+    if act != ACT_NONE and not dy_masked:
         g, sg = ops.act_bwd_sum(dy, y, act, 0.0, need_g=True, need_sum=need_sum, out_sum=ob)
     else:
         g = dy
-        sg = ops.channel_sum(dy, out=ob) if need_sum else None
+        sg = ops.act_bwd_sum(dy, None, ACT_NONE, need_g=False, need_sum=True, out_sum=ob)[1] if need_sum else None
     if want_b:
         tape.add_grad(bn.bias, sg)
     if want_w or want_g:
@@ -388,7 +392,7 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None):
     dx = None
     if need_dx:
         dx = ops.conv2d_dgrad(g, f.w_scaled, x.shape[2:], conv.stride, conv.padding, residual=residual,
-                              w_krsc=f.w_scaled_krsc)
+                              w_krsc=f.w_scaled_krsc, relu_mask=x if mask_input else None)
     return (dx, g) if has_res else dx
 
 

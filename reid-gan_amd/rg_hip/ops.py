@@ -106,7 +106,7 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
 
 
 def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0,
-                 w_krsc=None):
+                 w_krsc=None, relu_mask=None):
     """dx[N][C][H][W] from dy[N][K][P][Q] and w[K][C][KH][KW]; x_hw = (H, W) of the conv input.
     Also the forward of ConvTranspose2d (weight [in=K][out=C][KH][KW], output size x_hw)."""
     dy, w = _chk(dy, "dy"), _chk(w, "w")
@@ -125,8 +125,12 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
         w_krsc = weights_to_krsc(w)
     nbytes = lib.rg_conv2d_dgrad_workspace(N, C, H, W, K, KH, KW, sh, sw)
     ws = workspace(nbytes, dy.device) if nbytes else None
+    relu_mask = _chk(relu_mask, "relu_mask")
+    if relu_mask is not None and relu_mask.shape != dx.shape:
+        raise ValueError("conv2d_dgrad: relu_mask shape mismatch")
     lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(w_krsc), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale),
-                        _p(shift), _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
+                        _p(shift), _p(residual), act, slope, _p(relu_mask), _p(ws), ws.numel() if ws is not None else 0,
+                        _stream())
     return dx
 
 

@@ -43,13 +43,16 @@ class Bottleneck(RGModule):
             idn = x
         return rnn.conv_bn_tf(tape, self.conv3, self.bn3, o, residual=idn, act=ACT_RELU)   # conv3 + bn3 + add + relu
 
-    def tb(self, tape, dy, need_dx=True):
-        d, d_idn = rnn.conv_bn_tb(tape, self.conv3, self.bn3, dy)
+    def tb(self, tape, dy, need_dx=True, dy_masked=False, mask_input=False):
+        """dy_masked: dy already went through this block's final ReLU backward; mask_input: the block's input is the
+        previous block's ReLU output, whose backward is applied in conv1's dgrad epilogue (see nn.conv_bn_tb)."""
+        d, d_idn = rnn.conv_bn_tb(tape, self.conv3, self.bn3, dy, dy_masked=dy_masked, mask_input=True)
         if self.downsample is not None:
             d_idn = rnn.conv_bn_tb(tape, self.downsample[0], self.downsample[1], d_idn, need_dx=need_dx)
-        d = rnn.conv_bn_tb(tape, self.conv2, self.bn2, d)
-        # the skip gradient is added in the dgrad epilogue of conv1 (no separate add kernel)
-        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None)
+        d = rnn.conv_bn_tb(tape, self.conv2, self.bn2, d, dy_masked=True, mask_input=True)
+        # the skip gradient is added (and the ReLU backward of the block below applied) in the dgrad epilogue of conv1
+        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None,
+                              dy_masked=True, mask_input=mask_input)
 
 
 class BasicBlock(RGModule):
@@ -73,11 +76,12 @@ class BasicBlock(RGModule):
             idn = x
         return rnn.conv_bn_tf(tape, self.conv2, self.bn2, o, residual=idn, act=ACT_RELU)
 
-    def tb(self, tape, dy, need_dx=True):
-        d, d_idn = rnn.conv_bn_tb(tape, self.conv2, self.bn2, dy)
+    def tb(self, tape, dy, need_dx=True, dy_masked=False, mask_input=False):
+        d, d_idn = rnn.conv_bn_tb(tape, self.conv2, self.bn2, dy, dy_masked=dy_masked, mask_input=True)
         if self.downsample is not None:
             d_idn = rnn.conv_bn_tb(tape, self.downsample[0], self.downsample[1], d_idn, need_dx=need_dx)
-        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None)
+        return rnn.conv_bn_tb(tape, self.conv1, self.bn1, d, need_dx=need_dx, residual=d_idn if need_dx else None,
+                              dy_masked=True, mask_input=mask_input)
 
 
 _CFG = {
@@ -163,8 +167,11 @@ def trunk_tf(tape, mods, x):
 
 def trunk_tb(tape, mods, dy, need_dx=True):
     conv1, bn1, _relu, maxpool = mods[0], mods[1], mods[2], mods[3]
-    for layer in reversed(mods[4:]):
-        dy = layer.tb(tape, dy)
+    blocks = [blk for layer in mods[4:] for blk in layer]
+    for i in range(len(blocks) - 1, -1, -1):
+        # every block's input except the first one's (the max-pool output) is the previous block's ReLU output: its
+        # backward runs in this block's conv1 dgrad epilogue, so the block below receives an already masked gradient
+        dy = blocks[i].tb(tape, dy, dy_masked=(i != len(blocks) - 1), mask_input=(i != 0))
     dy = maxpool.tb(tape, dy)
     return rnn.conv_bn_tb(tape, conv1, bn1, dy, need_dx=need_dx)
 
