@@ -47,16 +47,17 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // gather form (no atomics, deterministic): each input pixel sums dy of the windows that selected it
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
-                                   float* __restrict__ dx, int64_t total, int H, int W, int P, int Q, int KH, int KW,
-                                   int SH, int SW, int PH, int PW) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W);
-        const int64_t t = i / W;
-        const int h = (int)(t % H);
-        const int64_t plane = t / H;
-        const float* gp = dy + plane * P * Q;
-        const unsigned char* ap = arg + plane * P * Q;
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                          float* __restrict__ dx, int H, int W, int P, int Q, int KH, int KW,
+                                                          int SH, int SW, int PH, int PW) {
+    // grid: (pixel blocks of one plane, planes) — 32-bit index math only
+    const int plane = blockIdx.y;
+    const int HW = H * W;
+    const float* gp = dy + (int64_t)plane * P * Q;
+    const unsigned char* ap = arg + (int64_t)plane * P * Q;
+    float* dxp = dx + (int64_t)plane * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const int h = i / W, w = i - h * W;
         float acc = 0.f;
         // windows p with p*SH - PH <= h <= p*SH - PH + KH - 1
         int p_lo = (h + PH - KH + 1 + SH - 1);
@@ -74,7 +75,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
                 if (ap[p * Q + q] == (unsigned char)(r * KW + s)) acc += gp[p * Q + q];
             }
         }
-        dx[i] = acc;
+        dxp[i] = acc;
     }
 }
 
@@ -167,8 +168,15 @@ extern "C" int rg_maxpool2d_bwd(const float* dy, const unsigned char* argmax, fl
     RG_REQUIRE(dy && dx && argmax && N > 0 && C > 0, "rg_maxpool2d_bwd: bad arguments");
     const int64_t total = (int64_t)N * C * H * W;
     rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 4.0 * N * C * ((double)H * W + 1.25 * P * Q));
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, argmax, dx, total, H, W, P,
-                       Q, KH, KW, SH, SW, PH, PW);
+    RG_REQUIRE((int64_t)N * C <= 65535 * 1024ll, "rg_maxpool2d_bwd: too many planes");
+    int gx = rg::cdiv(H * W, 256);
+    if (gx > 64) gx = 64;
+    int64_t planes = (int64_t)N * C;
+    // grid.y is limited to 65535: fold the excess into z
+    const int gy = planes > 65535 ? 65535 : (int)planes;
+    RG_REQUIRE(planes <= 65535, "rg_maxpool2d_bwd: N*C > 65535 planes");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gx, gy), dim3(256), 0, stream, dy, argmax, dx, H, W, P, Q, KH, KW, SH, SW,
+                       PH, PW);
     return rg::check_launch("rg_maxpool2d_bwd");
 }
 

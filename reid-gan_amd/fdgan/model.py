@@ -255,14 +255,14 @@ class FDGANModel(object):
                 main = torch.cuda.current_stream()
                 aux.wait_stream(main)
                 with torch.cuda.stream(aux):
-                    pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
+                    pred_fake_Dp = self.net_Dp(self.posemap, self.fake)
                     loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
                 _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
                 loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
                 main.wait_stream(aux)
             else:
                 _, _, pred_fake_Di = self.net_Di(self.origin, self.fake)
-                pred_fake_Dp = self.net_Dp(_CatPose.apply(self.posemap, self.fake))
+                pred_fake_Dp = self.net_Dp(self.posemap, self.fake)
                 loss_G_GAN_Di = self.criterionGAN_G(pred_fake_Di, True)
                 loss_G_GAN_Dp = self.criterionGAN_G(pred_fake_Dp, True)
 

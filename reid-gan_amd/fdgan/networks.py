@@ -283,7 +283,14 @@ class NLayerDiscriminator(RGModule):
             groups.append((conv, norm, act, slope))
         return groups
 
-    def tf(self, tape, x):
+    def tf(self, tape, x, image=None):
+        """forward(x) as the reference; forward(posemap, image) concatenates the two along channels inside the program
+        (FD/fdgan/model.py:160-161,197) so that the backward can stop at the image channels."""
+        split = None
+        if image is not None:
+            split = (x.shape[1], x.shape[1] + image.shape[1])
+            x = ops.cat_channels([x, image])
+        tape.push(split)
         for conv, norm, act, slope in self._groups():
             if norm is None:
                 x = conv.tf(tape, x, act=act, slope=slope)
@@ -293,9 +300,31 @@ class NLayerDiscriminator(RGModule):
 
     def tb(self, tape, dy, need_dx=True):
         groups = self._groups()
-        for gi in range(len(groups) - 1, -1, -1):
+        for gi in range(len(groups) - 1, 0, -1):
             conv, norm, _, _ = groups[gi]
             if norm is not None:
                 dy = norm.tb(tape, dy)
-            dy = conv.tb(tape, dy, need_dx=(need_dx or gi > 0))
-        return dy
+            dy = conv.tb(tape, dy, need_dx=True)
+        conv, norm, _, _ = groups[0]
+        if norm is not None:
+            dy = norm.tb(tape, dy)
+        split = tape.stack[-2] if len(tape.stack) >= 2 else None          # pushed before the first conv's record
+        if split is None:
+            dx = conv.tb(tape, dy, need_dx=need_dx)
+            tape.pop()
+            return dx
+        ni = tape.needs_input
+        need_pose = ni is None or bool(ni[0])
+        need_img = ni is None or len(ni) < 2 or bool(ni[1])
+        c0, c1 = split
+        if need_pose or not need_img:
+            dx = conv.tb(tape, dy, need_dx=need_dx and (need_pose or need_img))
+            tape.pop()
+            if dx is None:
+                return None, None
+            return (ops.slice_channels(dx, 0, c0) if need_pose else None,
+                    ops.slice_channels(dx, c0, c1) if need_img else None)
+        # only the image receives a gradient (the generator update): data gradient of the image channels alone
+        d_img = conv.tb(tape, dy, need_dx=need_dx, dx_channels=(c0, c1))
+        tape.pop()
+        return None, d_img

@@ -67,9 +67,10 @@ class Conv2d(RGModule, _KrscCache):
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
-    def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False):
+    def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False, dx_channels=None):
         """mask_input: the conv's input x is the ReLU output of the layer below — its backward (zero where x <= 0) is
-        applied to dx (+ residual) in the dgrad epilogue."""
+        applied to dx (+ residual) in the dgrad epilogue.  dx_channels=(c0, c1): only that channel range of the input
+        receives a gradient (the rest of a concatenated input is constant) -> dx has c1 - c0 channels."""
         x, y, act, slope = tape.pop()
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
@@ -80,6 +81,9 @@ class Conv2d(RGModule, _KrscCache):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
+        if dx_channels is not None:
+            c0, c1 = dx_channels
+            return ops.conv2d_dgrad(dy, self.weight.detach()[:, c0:c1].contiguous(), x.shape[2:], self.stride, self.padding)
         return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual,
                                 w_krsc=self._krsc(), relu_mask=x if mask_input else None)
 
