@@ -134,6 +134,10 @@ int rg_bicubic_normalize_fwd(const float* x, float* y, int N, int C, int H, int 
 int rg_bicubic_normalize_bwd(const float* dy, float* dx, int N, int C, int H, int W, int OH, int OW, const float* stdv,
                              rg_stream_t stream);
 
+/* ClusterMemory_Gradient.update_clusters, CC/clustercontrast/models/cm.py:184-190: g[id][:] /= |g[id]| + eps for every id of
+ * the int64 device list (each distinct id once) */
+int rg_normalize_listed_rows(float* g, const void* ids, int n_ids, int rows, int D, float eps, rg_stream_t stream);
+
 /* ---- conv + frozen-statistics BatchNorm fold (E / D_id of FD-GAN: set_bn_fix, FD/fdgan/networks.py:57-60 with
  * trainable affine parameters, model.py:72-85).  Forward: rg_conv2d_fwd with scale/shift from rg_bn_fold — the
  * pre-normalisation tensor is never written.  Backward without it:

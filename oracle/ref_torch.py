@@ -416,6 +416,59 @@ class OCMHard(torch.autograd.Function):
         return grad_inputs, None, None, None
 
 
+class OCMGan(torch.autograd.Function):
+    """CM_gan, CC/clustercontrast/models/cm.py:83-108: the ReID bank and a second bank of GAN-side features are updated
+    together, in batch order; the second one is re-normalised with F.normalize (eps-clamped)."""
+
+    @staticmethod
+    def forward(ctx, inputs, gan_inputs, targets, features, gan_features, momentum):
+        ctx.features, ctx.gan_features, ctx.momentum = features, gan_features, momentum
+        ctx.save_for_backward(inputs, gan_inputs, targets)
+        return inputs.mm(features.t())
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        inputs, gan_inputs, targets = ctx.saved_tensors
+        grad_inputs = grad_outputs.mm(ctx.features) if ctx.needs_input_grad[0] else None
+        for x, gx, y in zip(inputs, gan_inputs, targets):
+            ctx.features[y] = ctx.momentum * ctx.features[y] + (1. - ctx.momentum) * x
+            ctx.features[y] /= ctx.features[y].norm()
+            ctx.gan_features[y] = ctx.momentum * ctx.gan_features[y] + (1. - ctx.momentum) * gx
+            ctx.gan_features[y] = F.normalize(ctx.gan_features[y], dim=0)
+        return grad_inputs, None, None, None, None, None
+
+
+class OClusterMemoryGradient(object):
+    """ClusterMemory_Gradient, cm.py:138-193, without the hard-coded .cuda(): centroids are a leaf tensor trained by their
+    own SGD; the loss sees the DETACHED normalised copy (so gradients reach the centroids only through other paths)."""
+
+    def __init__(self, temp=0.05):
+        self.temp = temp
+
+    def set_clusters(self, clusters, cluster_lr):
+        self.trainable_clusters = clusters.detach().clone().requires_grad_(True)
+        self.optimizer_cluster = torch.optim.SGD([self.trainable_clusters], lr=cluster_lr)
+        self.normed_clusters = F.normalize(self.trainable_clusters)
+
+    def forward(self, inputs, targets, ex_f=None):
+        inputs = F.normalize(inputs, dim=1)
+        outputs = torch.mm(inputs, self.normed_clusters.detach().clone().t())
+        if ex_f is not None:
+            ex_f = F.normalize(ex_f, dim=1)
+            outputs_ex = torch.mm(inputs, ex_f.t())
+            group_size = outputs_ex.shape[0] // outputs_ex.shape[1]
+            outputs_ex = outputs_ex + (-10000.0 * torch.eye(ex_f.shape[0])).repeat_interleave(group_size, dim=0)
+            outputs = torch.cat([outputs, outputs_ex], dim=1)
+        return F.cross_entropy(outputs / self.temp, targets)
+
+    def update_clusters(self, p_ids, eps=1e-16):
+        for p_id in p_ids:
+            self.trainable_clusters.grad[p_id] /= self.trainable_clusters.grad[p_id].norm() + eps
+        self.optimizer_cluster.step()
+        self.optimizer_cluster.zero_grad()
+        self.normed_clusters = F.normalize(self.trainable_clusters)
+
+
 class OClusterMemory(nn.Module):
     """ClusterMemory.forward (cm.py:123-137) without the hard-coded .cuda()."""
 

@@ -164,9 +164,8 @@ class ClusterMemory_Gradient(nn.Module, ABC):
 
     def update_clusters(self, p_ids, eps=1e-16):
         g = self.trainable_clusters.grad
-        rows = g[p_ids]
-        nrm = ops.l2norm_rows_fwd(rows.contiguous(), eps)[1]
-        g[p_ids] = rows / (nrm.view(-1, 1) + eps)
+        ids = torch.as_tensor(p_ids, dtype=torch.int64).to(g.device).reshape(-1).contiguous()
+        ops.normalize_listed_rows(g, ids, eps)
         self.optimizer_cluster.step()
         self.optimizer_cluster.zero_grad()
         self.normed_clusters = ops.l2norm_rows_fwd(self.trainable_clusters.detach())[0]

@@ -137,3 +137,32 @@ extern "C" int rg_cm_update_hard(const float* inputs, const int64_t* targets, fl
                        momentum);
     return rg::check_launch("rg_cm_update_hard");
 }
+
+// ClusterMemory_Gradient.update_clusters (CC/clustercontrast/models/cm.py:184-190): g[id] /= |g[id]| + eps for every listed
+// row, one wave per listed row.  A row listed twice is divided twice on the reference's sequential loop; the second
+// division is by 1 + eps up to rounding, so rows are de-duplicated here by letting only the first occurrence act.
+namespace {
+__global__ __launch_bounds__(256) void normalize_listed_rows_kernel(float* __restrict__ g, const long long* __restrict__ ids,
+                                                                    int n_ids, int rows, int D, float eps) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n_ids) return;
+    const long long id = ids[j];
+    if (id < 0 || id >= rows) return;
+    for (int t = 0; t < j; ++t)
+        if (ids[t] == id) return;                    // wave-uniform
+    float* r = g + id * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += r[d] * r[d];
+    s = rg_wave_sum(s);
+    const float inv = 1.f / (sqrtf(s) + eps);
+    for (int d = lane; d < D; d += 64) r[d] *= inv;
+}
+}  // namespace
+
+extern "C" int rg_normalize_listed_rows(float* g, const void* ids, int n_ids, int rows, int D, float eps, hipStream_t stream) {
+    RG_REQUIRE(g && ids && n_ids > 0 && rows > 0 && D > 0, "rg_normalize_listed_rows: bad arguments");
+    rg::ProfScope prof(rg::FAM_CM, stream, 0.0, 8.0 * n_ids * (double)D);
+    hipLaunchKernelGGL(normalize_listed_rows_kernel, dim3(rg::cdiv(n_ids, 4)), dim3(256), 0, stream, g,
+                       static_cast<const long long*>(ids), n_ids, rows, D, eps);
+    return rg::check_launch("rg_normalize_listed_rows");
+}

@@ -752,6 +752,14 @@ def cm_update(inputs, targets, features, momentum, hard=False, normalize_eps=Fal
 # ------------------------------------------------------------------------------------------------
 # optimizers
 # ------------------------------------------------------------------------------------------------
+def normalize_listed_rows(g, ids, eps=1e-16):
+    """in place: g[id] /= |g[id]| + eps for the listed (int64, device) row ids"""
+    g = _chk(g, "g")
+    ids = _chk(ids, "ids", torch.int64)
+    lib.rg_normalize_listed_rows(_p(g), _p(ids), ids.numel(), g.shape[0], g.shape[1], eps, _stream())
+    return g
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     lib.rg_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                      _stream())

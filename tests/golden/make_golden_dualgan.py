@@ -131,6 +131,30 @@ def main():
         vals += [crit(pred, real, True).item(), crit(pred, real, False).mean().item()]
     out["lsgan"] = np.array(vals)
 
+    print("CM_gan (clustercontrast/models/cm.py, loaded by path)")
+    import importlib.util
+    from oracle import ref_torch as O
+    from tests.golden import cases as C0
+    spec = importlib.util.spec_from_file_location("ref_cc_cm", os.path.join(CC, "clustercontrast/models/cm.py"))
+    ref_cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_cm)
+    bank, feats, labels, gout = C0.cm_case()
+    gbank = torch.nn.functional.normalize(bank.flip(0) + 0.1, dim=1)
+    gfeat = feats.flip(1) * 3.0 + 0.2
+    res = []
+    for fn in (O.OCMGan, ref_cm.CM_gan):
+        b1, b2 = bank.clone(), gbank.clone()
+        x = feats.clone().requires_grad_(True)
+        y = fn.apply(x, gfeat, labels, b1, b2, torch.Tensor([0.2]))
+        y.backward(gout)
+        res.append((y.detach(), x.grad, b1, b2))
+    for a, b, what in zip(res[0], res[1], ("logits", "grad", "bank", "gan_bank")):
+        check(a, b, "cm_gan " + what)
+    out["cm_gan_logits"], _ = sub(res[1][0])
+    out["cm_gan_grad"], _ = sub(res[1][1])
+    out["cm_gan_bank"], _ = sub(res[1][2])
+    out["cm_gan_gbank"], _ = sub(res[1][3])
+
     print("bicubic + normalize (torch anchor)")
     x = C.bicubic_case()
     y = D.o_my_transform(x, (64, 32))

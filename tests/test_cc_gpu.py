@@ -163,3 +163,60 @@ def test_cc_trainer_three_steps(dev):
         assert abs(lr - lo) <= 1e-3 * abs(lo), "step %d loss %r vs %r" % (it, lr, lo)
         # the rows written into the bank are features of weights that went through `it` Adam steps
         _check_l2(rm.features, om.features, 1e-3 if it == 0 else 3e-3, "bank after step %d" % it)
+
+
+def test_cm_gan(dev):
+    """cm_gan(): logits, input gradient and BOTH banks (ReID features, GAN features) after the ordered update."""
+    import torch.nn.functional as F
+    from oracle import ref_torch as O
+    from clustercontrast.models import cm as M
+    from tests.golden import cases as C
+    bank, feats, labels, gout = C.cm_case()
+    gbank = F.normalize(bank.flip(0) + 0.1, dim=1)
+    gfeat = feats.flip(1) * 3.0 + 0.2
+    bo, go = bank.clone(), gbank.clone()
+    br, gr = bank.clone().to(dev), gbank.clone().to(dev)
+    xo, xr = feats.clone().requires_grad_(True), feats.clone().to(dev).requires_grad_(True)
+    yo = O.OCMGan.apply(xo, gfeat, labels, bo, go, torch.Tensor([0.2]))
+    yr = M.cm_gan(xr, gfeat.to(dev), labels.to(dev), br, gr, 0.2)
+    yo.backward(gout)
+    yr.backward(gout.to(dev))
+    _check(yr, yo, 1e-5, "logits")
+    _check(xr.grad, xo.grad, 1e-5, "grad")
+    _check(br, bo, 1e-5, "bank")
+    _check(gr, go, 1e-5, "gan bank")
+
+
+def test_cluster_memory_gradient(dev):
+    """ClusterMemory_Gradient: loss (with and without the extra negatives), gradient to the inputs, and the centroid
+    update (listed rows of the gradient normalised, SGD step, re-normalised copy)."""
+    import torch.nn.functional as F
+    from oracle import ref_torch as O
+    from clustercontrast.models.cm import ClusterMemory_Gradient
+    g = torch.Generator().manual_seed(9)
+    K, D, B = 12, 64, 16
+    clusters = torch.randn(K, D, generator=g)
+    om = O.OClusterMemoryGradient(temp=0.05)
+    om.set_clusters(clusters, 0.1)
+    rm = ClusterMemory_Gradient(D, K, temp=0.05)
+    rm.set_clusters(clusters.to(dev), 0.1)
+    labels = torch.randint(0, K, (B,), generator=g)
+    x = torch.randn(B, D, generator=g)
+    ex = torch.randn(4, D, generator=g)                     # 4 extra negatives, group size 4
+    for ex_f in (None, ex):
+        xo, xr = x.clone().requires_grad_(True), x.clone().to(dev).requires_grad_(True)
+        lo = om.forward(xo, labels, ex_f)
+        lr = rm(xr, labels.to(dev), None if ex_f is None else ex_f.to(dev))
+        assert abs(lr.item() - lo.item()) <= 1e-4 * abs(lo.item()), (lr.item(), lo.item())
+        lo.backward()
+        lr.backward()
+        _check(xr.grad, xo.grad, 1e-4, "d inputs")
+    # centroid update from an externally produced gradient (the reference fills .grad through the GAN loss)
+    gc = torch.randn(K, D, generator=g)
+    om.trainable_clusters.grad = gc.clone()
+    rm.trainable_clusters.grad = gc.clone().to(dev)
+    ids = [3, 7, 3, 0]
+    om.update_clusters(ids)
+    rm.update_clusters(ids)
+    _check(rm.trainable_clusters, om.trainable_clusters, 1e-5, "clusters after the step")
+    _check(rm.normed_clusters, om.normed_clusters, 1e-5, "normalised clusters")

@@ -66,3 +66,19 @@ def test_lsgan_and_bicubic():
     s, st = sub(D.o_my_transform(C.bicubic_case(), (64, 32)))
     _cmp(s, "bicubic_normalize")
     _cmp(st, "bicubic_normalize_stats")
+
+
+def test_cm_gan():
+    import torch.nn.functional as F
+    from oracle import ref_torch as O
+    from tests.golden import cases as C0
+    bank, feats, labels, gout = C0.cm_case()
+    gbank = F.normalize(bank.flip(0) + 0.1, dim=1)
+    gfeat = feats.flip(1) * 3.0 + 0.2
+    x = feats.clone().requires_grad_(True)
+    y = O.OCMGan.apply(x, gfeat, labels, bank, gbank, torch.Tensor([0.2]))
+    y.backward(gout)
+    _cmp(sub(y.detach())[0], "cm_gan_logits")
+    _cmp(sub(x.grad)[0], "cm_gan_grad")
+    _cmp(sub(bank)[0], "cm_gan_bank")
+    _cmp(sub(gbank)[0], "cm_gan_gbank")
