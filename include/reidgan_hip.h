@@ -186,6 +186,13 @@ int rg_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int6
 int rg_softmax_rows_fwd(const float* x, float* y, int rows, int cols, float scale, rg_stream_t stream);
 int rg_softmax_rows_bwd(const float* p, const float* dp, float* ds, int rows, int cols, float scale, rg_stream_t stream);
 
+/* AEModel.hard_mix, CC/dual_gan/models/AE_model.py:274-292: out[j] = lam * src[idx_a[j]] + (1 - lam) * src[idx_b[j]] over rows
+ * of `len` floats; idx_* are int64 device arrays of rows_out entries.  Backward: dsrc[r] = sum over the rows that read r. */
+int rg_mix_rows_fwd(const float* src, const void* idx_a, const void* idx_b, float lam, float* out, int rows_src,
+                    int rows_out, int64_t len, rg_stream_t stream);
+int rg_mix_rows_bwd(const float* g, const void* idx_a, const void* idx_b, float lam, float* dsrc, int rows_src, int rows_out,
+                    int64_t len, rg_stream_t stream);
+
 /* ---- pooling -------------------------------------------------------------------------------- */
 int rg_maxpool2d_fwd(const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W, int KH, int KW,
                      int SH, int SW, int PH, int PW, int P, int Q, rg_stream_t stream);

@@ -89,6 +89,69 @@ class OOutput(nn.Module):
         return self.model(x)
 
 
+class OResBlock(nn.Module):
+    """base_function.py:193-233, sample_type 'none'"""
+
+    def __init__(self, cin, cout, hidden, norm):
+        super(OResBlock, self).__init__()
+        self.conv1 = nn.Conv2d(cin, hidden, 3, 1, 1)
+        self.conv2 = nn.Conv2d(hidden, cout, 3, 1, 1)
+        self.bypass = nn.Conv2d(cin, cout, 1)
+        self.model = nn.Sequential(_norm2d(norm, cin), _act(), self.conv1, _norm2d(norm, hidden), _act(), self.conv2)
+        self.shortcut = nn.Sequential(self.bypass)
+
+    def forward(self, x):
+        return self.model(x) + self.shortcut(x)
+
+
+class OAEGenerator(nn.Module):
+    """networks.py:278-355"""
+
+    def __init__(self, image_nc=3, ngf=64, img_f=256, layers=3, norm='instance', output_nc=3, num_blocks=3):
+        super(OAEGenerator, self).__init__()
+        self.layers, self.num_blocks = layers, num_blocks
+        self.block0 = OEncoderBlockOptimized(image_nc, ngf, norm)
+        mult = 1
+        for i in range(layers - 1):
+            prev, mult = mult, min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder%d' % i, OEncoderBlock(ngf * prev, ngf * mult, norm))
+        for i in range(num_blocks):
+            setattr(self, 'mblock%d' % i, OResBlock(ngf * mult, ngf * mult, ngf * mult, norm))
+        for i in range(layers):
+            prev = mult
+            mult = min(2 ** (layers - i - 2), img_f // ngf) if i != layers - 1 else 1
+            setattr(self, 'decoder%d' % i, OResBlockDecoder(ngf * prev, ngf * mult, ngf * mult, norm))
+        self.outconv = OOutput(ngf, output_nc, 3)
+
+    def forward_enc(self, x):
+        x = self.block0(x)
+        for i in range(self.layers - 1):
+            x = getattr(self, 'encoder%d' % i)(x)
+        return x
+
+    def forward_dec(self, f):
+        for i in range(self.num_blocks):
+            f = getattr(self, 'mblock%d' % i)(f)
+        for i in range(self.layers):
+            f = getattr(self, 'decoder%d' % i)(f)
+        return self.outconv(f)
+
+    def forward(self, x):
+        return self.forward_dec(self.forward_enc(x))
+
+
+def o_hard_mix(F_s, reid_f, group_size, lambda_fus):
+    """AE_model.py:274-292"""
+    fdim = reid_f.shape[1]
+    anchor = F.normalize(torch.mean(reid_f.reshape(-1, group_size, fdim), dim=1))
+    inst = F.normalize(reid_f)
+    sim = torch.exp(torch.einsum('n c, m c -> n m', anchor, inst))
+    id_mask = torch.eye(anchor.shape[0]).repeat_interleave(group_size, dim=1)
+    in_id = torch.argmin(id_mask * sim + (1 - id_mask) * torch.max(sim), dim=1)
+    out_id = torch.argmax((1 - id_mask) * sim, dim=1)
+    return lambda_fus * F_s[in_id] + (1 - lambda_fus) * F_s[out_id]
+
+
 # ---- Pose Transformer Module, PTM.py:6-58, 115-247 ----------------------------------------------------------------
 class OCAB(nn.Module):
     def __init__(self, d, nhead, ff):

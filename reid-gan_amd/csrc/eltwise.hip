@@ -255,3 +255,51 @@ extern "C" int rg_copy_channels(const float* src, float* dst, int N, int Cc, int
                        sc0, Cd, dc0, accumulate);
     return rg::check_launch("rg_copy_channels");
 }
+
+// AEModel.hard_mix, CC/dual_gan/models/AE_model.py:274-292: out[j] = lam * src[ia[j]] + (1 - lam) * src[ib[j]] over rows of
+// `len` floats (feature maps of the image encoder).  The backward gathers per SOURCE row (deterministic, no atomics).
+namespace {
+__global__ void mix_rows_fwd_kernel(const float* __restrict__ src, const long long* __restrict__ ia,
+                                    const long long* __restrict__ ib, float lam, float* __restrict__ out, int64_t len,
+                                    int64_t total) {
+    RG_GRID_STRIDE(i, total) {
+        const int64_t j = i / len, e = i - j * len;
+        out[i] = lam * src[ia[j] * len + e] + (1.f - lam) * src[ib[j] * len + e];
+    }
+}
+__global__ void mix_rows_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ ia,
+                                    const long long* __restrict__ ib, float lam, float* __restrict__ dsrc, int rows_out,
+                                    int64_t len, int64_t total) {
+    RG_GRID_STRIDE(i, total) {
+        const int64_t r = i / len, e = i - r * len;
+        float acc = 0.f;
+        for (int j = 0; j < rows_out; ++j) {
+            const float gv = g[(int64_t)j * len + e];
+            if (ia[j] == r) acc += lam * gv;
+            if (ib[j] == r) acc += (1.f - lam) * gv;
+        }
+        dsrc[i] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int rg_mix_rows_fwd(const float* src, const void* idx_a, const void* idx_b, float lam, float* out, int rows_src,
+                               int rows_out, int64_t len, hipStream_t stream) {
+    RG_REQUIRE(src && idx_a && idx_b && out && rows_src > 0 && rows_out > 0 && len > 0, "rg_mix_rows_fwd: bad arguments");
+    const int64_t total = (int64_t)rows_out * len;
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 12.0 * total);
+    hipLaunchKernelGGL(mix_rows_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, src,
+                       static_cast<const long long*>(idx_a), static_cast<const long long*>(idx_b), lam, out, len, total);
+    return rg::check_launch("rg_mix_rows_fwd");
+}
+
+extern "C" int rg_mix_rows_bwd(const float* g, const void* idx_a, const void* idx_b, float lam, float* dsrc, int rows_src,
+                               int rows_out, int64_t len, hipStream_t stream) {
+    RG_REQUIRE(g && idx_a && idx_b && dsrc && rows_src > 0 && rows_out > 0 && len > 0, "rg_mix_rows_bwd: bad arguments");
+    const int64_t total = (int64_t)rows_src * len;
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 4.0 * total * (1.0 + rows_out));
+    hipLaunchKernelGGL(mix_rows_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g,
+                       static_cast<const long long*>(idx_a), static_cast<const long long*>(idx_b), lam, dsrc, rows_out, len,
+                       total);
+    return rg::check_launch("rg_mix_rows_bwd");
+}

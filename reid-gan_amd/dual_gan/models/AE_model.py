@@ -10,7 +10,8 @@ Scheduling differences that do not change results: the loss terms `mean(|fake - 
 optimizers are the fused arena Adam (rg_hip.optim) and their gradient arenas are all-reduced over RCCL when
 torch.distributed is initialised (the reference wraps the nets in nn.DataParallel, base_function.py:93-102).
 Every D forward runs its own spectral-norm power iteration, in the reference's order (G-loss pass, then real, then fake).
-Generators other than 'Pose' (networks.define_G), `--bipath_gan`, `--use_adp` and the VGG loss are not built yet.
+Generators: 'Pose' (joint step) and 'AE' (GAN warm-up / feature mixing); 'DPTN' etc., `--bipath_gan`, `--use_adp` and the
+VGG loss are not built yet.
 """
 from __future__ import absolute_import
 
@@ -21,6 +22,7 @@ from torch import nn
 
 from rg_hip import functional as RF
 from rg_hip import nn as rnn
+from rg_hip import ops
 from rg_hip import optim as roptim
 from rg_hip.parallel import GradReducer
 from . import base_function, external_function, networks
@@ -129,8 +131,39 @@ class AEModel(BaseModel):
             self.source_pose = source_pose.to(self.device, non_blocking=True).contiguous()
 
     def forward(self):
-        raise TypeError("AEModel.forward() calls net_G(source_image); the 'Pose' generator takes (features, pose) — "
-                        "use synthesize_p(features) (the reference fails the same way for model_gen='Pose')")
+        if self.opt.model_gen == 'Pose':
+            raise TypeError("AEModel.forward() calls net_G(source_image); the 'Pose' generator takes (features, pose) — "
+                            "use synthesize_p(features) (the reference fails the same way for model_gen='Pose')")
+        self.fake_image = self.net_G(self.source_image)
+
+    def synthesize(self, features):
+        self.fake_image = self.net_G(features)
+
+    def synthesize_fgan(self):
+        """detached encoder features of the source images (AE_model.py:251-254)"""
+        with torch.no_grad():
+            return self.net_G.module.forward_enc(self.source_image)
+
+    def synthesize_fc(self, reid_f, group_size=16):
+        """decode a hard mix of the source images' encoder features (AE_model.py:256-272)"""
+        F_s = self.net_G.module.forward_enc(self.source_image)
+        self.fake_image = self.net_G.module.forward_dec(self.hard_mix(F_s, reid_f, group_size))
+        return self.fake_image
+
+    def hard_mix(self, F_s, reid_f, group_size):
+        """lambda_fus * F_s[hardest in-identity sample] + (1 - lambda_fus) * F_s[nearest other-identity sample] per
+        identity group (AE_model.py:274-292).  The similarity GEMM and the mix run on HIP kernels; the two index
+        selections (exp / argmin / argmax over an [identities, batch] matrix) are selection logic, not arithmetic that
+        reaches the result."""
+        _, fdim = reid_f.shape
+        reid_f = reid_f.detach()
+        anchor = RF.normalize_rows(_group_mean(reid_f, group_size))
+        inst = RF.normalize_rows(reid_f.contiguous())
+        sim = torch.exp(ops.linear_fwd(anchor, inst))
+        id_mask = torch.eye(anchor.shape[0], device=sim.device).repeat_interleave(group_size, dim=1)
+        in_id = torch.argmin(id_mask * sim + (1 - id_mask) * torch.max(sim), dim=1)
+        out_id = torch.argmax((1 - id_mask) * sim, dim=1)
+        return _MixRows.apply(F_s, in_id, out_id, float(self.opt.lambda_fus))
 
     def synthesize_p(self, features):
         self.fake_image = self.net_G(features, self.source_pose)
@@ -204,6 +237,27 @@ class AEModel(BaseModel):
         self.optimizer_G.zero_grad()
         self.backward_G()
         self.optimizer_G.step()
+
+
+def _group_mean(x, group_size):
+    """mean over consecutive groups of rows: [n * g, D] -> [n, D] (a GEMM with a constant averaging matrix)"""
+    n = x.shape[0] // group_size
+    avg = torch.zeros(n, x.shape[0], device=x.device)
+    avg[torch.arange(x.shape[0], device=x.device) // group_size, torch.arange(x.shape[0], device=x.device)] = 1.0 / group_size
+    return ops.linear_fwd(avg, x.t().contiguous())
+
+
+class _MixRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, ia, ib, lam):
+        ctx.save_for_backward(ia, ib)
+        ctx.lam, ctx.shape = lam, src.shape
+        return ops.mix_rows_fwd(src, ia, ib, lam)
+
+    @staticmethod
+    def backward(ctx, g):
+        ia, ib = ctx.saved_tensors
+        return ops.mix_rows_bwd(g.contiguous(), ia, ib, ctx.lam, ctx.shape), None, None, None
 
 
 def _wrap_step(optimizer, reducer):

@@ -187,6 +187,62 @@ class _NormActConv(object):
         return ops.act_bwd(dy, y, act, slope)
 
 
+class ResBlock(RGModule):
+    """Residual block (base_function.py:193-233), sample_type 'none' (the only form the generators use):
+    out = conv3x3(act(norm(conv3x3(act(norm(x)))))) + conv1x1(x)."""
+
+    def __init__(self, input_nc, output_nc, hidden_nc=None, norm_layer=rnn.BatchNorm2d, nonlinearity=None,
+                 sample_type='none', use_spect=False, use_coord=False):
+        super(ResBlock, self).__init__()
+        nonlinearity = rnn.LeakyReLU() if nonlinearity is None else nonlinearity
+        hidden_nc = output_nc if hidden_nc is None else hidden_nc
+        self.sample = True
+        if sample_type == 'none':
+            self.sample = False
+        elif sample_type in ('up', 'down'):
+            raise NotImplementedError("ResBlock sample_type '%s' is not used by the generators of the training scripts"
+                                      % sample_type)
+        else:
+            raise NotImplementedError('sample type [%s] is not found' % sample_type)
+        kwargs = {'kernel_size': 3, 'stride': 1, 'padding': 1}
+        kwargs_short = {'kernel_size': 1, 'stride': 1, 'padding': 0}
+        self.conv1 = coord_conv(input_nc, hidden_nc, use_spect, use_coord, **kwargs)
+        self.conv2 = coord_conv(hidden_nc, output_nc, use_spect, use_coord, **kwargs)
+        self.bypass = coord_conv(input_nc, output_nc, use_spect, use_coord, **kwargs_short)
+        self._act = _slope(nonlinearity)
+        if norm_layer is None:
+            self.model = nn.Sequential(nonlinearity, self.conv1, nonlinearity, self.conv2,)
+            self._ix = (None, None)
+        else:
+            self.model = nn.Sequential(norm_layer(input_nc), nonlinearity, self.conv1, norm_layer(hidden_nc), nonlinearity,
+                                       self.conv2,)
+            self._ix = (0, 3)
+        self.shortcut = nn.Sequential(self.bypass,)
+
+    def tf(self, tape, x):
+        act, slope = self._act
+        n1, n2 = self._ix
+        m = self.model
+        sc = self.bypass.tf(tape, x)
+        a = _NormActConv.pre_tf(tape, m[n1] if n1 is not None else None, act, slope, x)
+        if n2 is None:
+            h = self.conv1.tf(tape, a, act=act, slope=slope)
+        else:
+            h = m[n2].tf(tape, self.conv1.tf(tape, a), act=act, slope=slope)
+        return self.conv2.tf(tape, h, residual=sc)
+
+    def tb(self, tape, dy, need_dx=True):
+        act, slope = self._act
+        n1, n2 = self._ix
+        m = self.model
+        d = self.conv2.tb(tape, dy)
+        if n2 is not None:
+            d = m[n2].tb(tape, d)
+        d = self.conv1.tb(tape, d)
+        d = _NormActConv.pre_tb(tape, m[n1] if n1 is not None else None, act, slope, d)
+        return self.bypass.tb(tape, dy, residual=d)
+
+
 class EncoderBlockOptimized(RGModule):
     """Encoder block for the first layer of the generator (base_function.py:236-257):
     conv 4x4/2 -> [norm] -> act -> conv 3x3."""

@@ -13,7 +13,7 @@ from torch import nn
 from rg_hip import nn as rnn
 from rg_hip import ops
 from rg_hip.tape import RGModule
-from .base_function import (EncoderBlock, EncoderBlockOptimized, FeatureAdaptBlock1, Output, ResBlockDecoder,
+from .base_function import (EncoderBlock, EncoderBlockOptimized, FeatureAdaptBlock1, Output, ResBlock, ResBlockDecoder,
                             ResBlockEncoder, ResBlockEncoderOptimized, SpectralNorm, get_nonlinearity_layer,
                             get_norm_layer, init_net, _slope)
 from .PTM import PCTM, PTM  # noqa: F401
@@ -28,9 +28,11 @@ def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='
     if opt.model_gen == 'Pose':
         netG = PoseGenerator1(ngf, pose_nc, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc,
                               affine, nhead, num_CABs, num_TTBs)
-    elif opt.model_gen in ('DPTN', 'AE', 'DEC', 'FD', 'PoseAE'):
-        raise NotImplementedError("generator '%s' is not built yet on the HIP path (only 'Pose', the generator of the "
-                                  "joint training step)" % opt.model_gen)
+    elif opt.model_gen == 'AE':
+        netG = AEGenerator(image_nc, ngf, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc, num_blocks)
+    elif opt.model_gen in ('DPTN', 'DEC', 'FD', 'PoseAE'):
+        raise NotImplementedError("generator '%s' is not built yet on the HIP path ('Pose' — the joint training step — and "
+                                  "'AE' are)" % opt.model_gen)
     else:
         raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
     return init_net(netG, opt.init_type)
@@ -53,6 +55,110 @@ def print_network(net):
 ##############################################################################
 # Generator
 ##############################################################################
+class _EncFn(torch.autograd.Function):
+    """One autograd node for a sub-program of a generator (forward_enc / forward_dec called on their own)."""
+
+    @staticmethod
+    def forward(ctx, net, which, x, *params):
+        from rg_hip.tape import Tape
+        tape = Tape(param_grad=len(params) > 0, needs_input=[x.requires_grad])
+        ctx.net, ctx.which, ctx.tape, ctx.params = net, which, tape, params
+        return getattr(net, which + "_tf")(tape, x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        from rg_hip import ops as _ops
+        _ops.side_begin()
+        try:
+            dx = getattr(ctx.net, ctx.which + "_tb")(ctx.tape, g.contiguous(), need_dx=ctx.needs_input_grad[2])
+        finally:
+            _ops.side_join()
+        grads = []
+        for p in ctx.params:
+            gp = ctx.tape.grads.get(id(p))
+            v = getattr(p, "_rg_grad", None)
+            if gp is not None and v is not None and gp.data_ptr() == v.data_ptr():
+                p.grad = v
+                gp = None
+            grads.append(gp)
+        return (None, None, dx) + tuple(grads)
+
+
+class AEGenerator(RGModule):
+    """Auto-encoder generator (networks.py:278-355): image encoder -> ResBlocks -> residual decoder -> Output."""
+
+    def __init__(self, image_nc, ngf=64, img_f=256, layers=3, norm='batch', activation='ReLU', use_spect=True,
+                 use_coord=False, output_nc=3, num_blocks=3):
+        super(AEGenerator, self).__init__()
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        self.block0 = EncoderBlockOptimized(image_nc, ngf, norm_layer, nonlinearity, use_spect, use_coord)
+        mult = 1
+        for i in range(self.layers - 1):
+            mult_prev = mult
+            mult = min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder' + str(i), EncoderBlock(ngf * mult_prev, ngf * mult, norm_layer, nonlinearity, use_spect,
+                                                           use_coord))
+        self.num_blocks = num_blocks
+        for i in range(num_blocks):
+            setattr(self, 'mblock' + str(i), ResBlock(ngf * mult, ngf * mult, norm_layer=norm_layer, nonlinearity=nonlinearity,
+                                                      use_spect=use_spect, use_coord=use_coord))
+        for i in range(self.layers):
+            mult_prev = mult
+            mult = min(2 ** (self.layers - i - 2), img_f // ngf) if i != self.layers - 1 else 1
+            setattr(self, 'decoder' + str(i), ResBlockDecoder(ngf * mult_prev, ngf * mult, ngf * mult, norm_layer, nonlinearity,
+                                                              use_spect, use_coord))
+        self.outconv = Output(ngf, output_nc, 3, None, nonlinearity, use_spect, use_coord)
+
+    def _enc(self):
+        return [self.block0] + [getattr(self, 'encoder' + str(i)) for i in range(self.layers - 1)]
+
+    def _dec(self):
+        return ([getattr(self, 'mblock' + str(i)) for i in range(self.num_blocks)] +
+                [getattr(self, 'decoder' + str(i)) for i in range(self.layers)] + [self.outconv])
+
+    def enc_tf(self, tape, x):
+        for m in self._enc():
+            x = m.tf(tape, x)
+        return x
+
+    def enc_tb(self, tape, dy, need_dx=True):
+        mods = self._enc()
+        for i in range(len(mods) - 1, -1, -1):
+            dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
+        return dy
+
+    def dec_tf(self, tape, x):
+        for m in self._dec():
+            x = m.tf(tape, x)
+        return x
+
+    def dec_tb(self, tape, dy, need_dx=True):
+        for m in reversed(self._dec()):
+            dy = m.tb(tape, dy)
+        return dy
+
+    def tf(self, tape, x):
+        return self.dec_tf(tape, self.enc_tf(tape, x))
+
+    def tb(self, tape, dy, need_dx=True):
+        return self.enc_tb(tape, self.dec_tb(tape, dy), need_dx=need_dx)
+
+    def _sub(self, which, x, mods):
+        params = [p for m in mods for p in m.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        if not params and not (torch.is_grad_enabled() and x.requires_grad):
+            from rg_hip.tape import Tape
+            return getattr(self, which + "_tf")(Tape(param_grad=False, record=False), x)
+        return _EncFn.apply(self, which, x, *params)
+
+    def forward_enc(self, source):
+        return self._sub("enc", source, self._enc())
+
+    def forward_dec(self, feature):
+        return self._sub("dec", feature, self._dec())
+
+
 class PoseGenerator1(RGModule):
     """Pose encoder -> PCTM(pose tokens attend to the adapted ReID feature map) -> residual decoder with skips
     (networks.py:639-738).  forward(reid_f [B, 2048, h, w], source_pose [B, pose_nc, H, W]) -> image [B, 3, H, W]."""

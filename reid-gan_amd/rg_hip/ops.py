@@ -562,6 +562,24 @@ def softmax_rows_bwd(p, dp, scale=1.0, out=None):
     return ds
 
 
+def mix_rows_fwd(src, ia, ib, lam):
+    src = _chk(src, "src")
+    ia, ib = _chk(ia, "idx_a", torch.int64), _chk(ib, "idx_b", torch.int64)
+    R, n = src.shape[0], ia.numel()
+    length = src.numel() // R
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    lib.rg_mix_rows_fwd(_p(src), _p(ia), _p(ib), lam, _p(out), R, n, length, _stream())
+    return out
+
+
+def mix_rows_bwd(g, ia, ib, lam, src_shape):
+    g = _chk(g, "g")
+    R, n = src_shape[0], ia.numel()
+    dsrc = torch.empty(tuple(src_shape), dtype=torch.float32, device=g.device)
+    lib.rg_mix_rows_bwd(_p(g), _p(ia), _p(ib), lam, _p(dsrc), R, n, dsrc.numel() // R, _stream())
+    return dsrc
+
+
 def cat_channels(tensors):
     """torch.cat(tensors, dim=1) for NCHW (or NC) tensors."""
     N = tensors[0].shape[0]

@@ -55,3 +55,11 @@ def lsgan_case():
 def bicubic_case():
     g = torch.Generator().manual_seed(96)
     return torch.rand(2, 3, 32, 16, generator=g)
+
+
+def aegen_case():
+    torch.manual_seed(75)
+    net = D.o_init_weights(D.OAEGenerator(3, 64, 256, 3, 'instance', 3, 3))
+    _perturb(net, 76)
+    net.train()
+    return net, D.synth_dualgan_inputs(2, 64, 32, seed=77)['Xs']

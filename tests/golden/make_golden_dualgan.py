@@ -103,6 +103,17 @@ def main():
         check(po[k].grad, pr[k].grad, "posegen1 grad " + k, 2e-4)
         out["posegen1_g_" + k], _ = sub(pr[k].grad)
 
+    print("AEGenerator")
+    on, x = C.aegen_case()
+    rn = ref_net.AEGenerator(3, 64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3)
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    yo, yr = on(x), rn(x)
+    check(yo, yr, "aegen_fwd")
+    check(on.forward_enc(x), rn.forward_enc(x), "aegen_enc")
+    out["aegen_fwd"], out["aegen_fwd_stats"] = sub(yr)
+    out["aegen_enc"], out["aegen_enc_stats"] = sub(rn.forward_enc(x))
+
     print("ResDiscriminator (spectral norm)")
     on, x = C.resdisc_case()
     rn = ref_net.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)

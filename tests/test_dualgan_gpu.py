@@ -137,7 +137,7 @@ def _gan_opt(**kw):
                num_blocks=3, nhead=2, num_CABs=2, num_TTBs=2, dis_layers=3, init_type="orthogonal", verbose=False,
                pool_size=0, gan_lr=2e-4, gan_mode="lsgan", no_vgg_loss=True, beta1=0.5, ratio_g2d=0.1, lambda_rec=2.0,
                lambda_g=5.0, gan_lr_policy="lambda", iter_start=0, niter=100, niter_decay=100, continue_train=False,
-               which_epoch="latest", bipath_gan=False, use_adp=False)
+               which_epoch="latest", bipath_gan=False, use_adp=False, lambda_fus=0.8)
     opt.update(kw)
     return argparse.Namespace(**opt)
 
@@ -241,5 +241,58 @@ def test_joint_step_4a(dev):
     assert abs(errs["D"] - lo_D.item()) <= 1e-3 * abs(lo_D.item()), (errs, lo_D.item())
     _check(model.fake_image, omodel.fake_image, 1e-3, "fake image")
     _check_l2(rm.features, om.features, 1e-3, "bank after the step")
+    _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params")
+    _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params")
+
+
+def test_aegenerator_and_gan_step(dev):
+    """model_gen='AE': AEGenerator forward / forward_enc / forward_dec against the oracle (== reference) and the
+    stand-alone GAN step AEModel.optimize_parameters() that GANTrainer.train_gan drives (trainers.py:286-335)."""
+    from dual_gan.models.models import create_model
+    from oracle import ref_dualgan as D
+    from tests.golden import cases_dualgan as C
+    from tests.golden.cases import sub
+    og, x = C.aegen_case()
+    od, _ = C.resdisc_case()
+    model = create_model(_gan_opt(model="AE", model_gen="AE"))
+    model.net_G.module.load_state_dict(og.state_dict())
+    model.net_D.module.load_state_dict(od.state_dict())
+    G = model.net_G.module
+    y = G(x.to(dev))
+    _check(y, og(x), 1e-3, "aegen fwd")
+    ref = GOLD["aegen_fwd"]
+    got = np.asarray(sub(y.detach().cpu())[0], dtype=np.float64).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+    # enc / dec as separate autograd nodes, gradients to the parameters of both halves
+    xo, xd = x.clone().requires_grad_(True), x.to(dev).requires_grad_(True)
+    fo, fd = og.forward_enc(xo), G.forward_enc(xd)
+    _check(fd, fo, 1e-3, "forward_enc")
+    yo, yd = og.forward_dec(fo), G.forward_dec(fd)
+    _check(yd, yo, 1e-3, "forward_dec")
+    g = torch.Generator().manual_seed(4)
+    dy = torch.randn(yo.shape, generator=g)
+    yo.backward(dy)
+    yd.backward(dy.to(dev))
+    _check_l2(xd.grad, xo.grad, 5e-3, "d image")
+    _check_grads(G, og, 5e-3, "aegen grads", tol_tensor=2e-2)
+    G.zero_grad()
+    og.zero_grad()
+    # hard_mix: same selections and mixture
+    f4o = og.forward_enc(D.synth_dualgan_inputs(4, 64, 32, seed=33)['Xs']).detach()
+    reid = torch.randn(4, 32, generator=g)
+    mo = D.o_hard_mix(f4o, reid, 2, 0.8)
+    mr = model.hard_mix(f4o.to(dev), reid.to(dev), 2)
+    _check(mr, mo, 1e-5, "hard_mix")
+    # stand-alone GAN step (D update, then G update) on an AE forward
+    omodel = D.OAEModel(og, od)
+    inp = D.synth_dualgan_inputs(4, 64, 32, seed=31)
+    omodel.set_input(inp)
+    omodel.fake_image = og(inp['Xs'])
+    omodel.optimize_generated()
+    model.set_input(inp)
+    model.optimize_parameters()
+    errs = model.get_current_errors()
+    assert abs(errs["D"] - omodel.loss_D.item()) <= 1e-3 * abs(omodel.loss_D.item()), (errs, omodel.loss_D.item())
+    assert abs(errs["G"] - omodel.loss_G.item()) <= 1e-3 * abs(omodel.loss_G.item()), (errs, omodel.loss_G.item())
     _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params")
     _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params")

@@ -82,3 +82,13 @@ def test_cm_gan():
     _cmp(sub(x.grad)[0], "cm_gan_grad")
     _cmp(sub(bank)[0], "cm_gan_bank")
     _cmp(sub(gbank)[0], "cm_gan_gbank")
+
+
+def test_aegenerator():
+    net, x = C.aegen_case()
+    s, st = sub(net(x))
+    _cmp(s, "aegen_fwd")
+    _cmp(st, "aegen_fwd_stats")
+    s, st = sub(net.forward_enc(x))
+    _cmp(s, "aegen_enc")
+    _cmp(st, "aegen_enc_stats")
