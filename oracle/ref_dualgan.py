@@ -219,6 +219,89 @@ class OPCTM(nn.Module):
         return hs.reshape(bs, c, h, w)
 
 
+class OPTM(nn.Module):
+    """PTM, PTM.py:60-112: src -> CABs = memory; tgt attends with key = memory, value = val"""
+
+    def __init__(self, d, nhead, n_cab, n_ttb, ff):
+        super(OPTM, self).__init__()
+        self.encoder = _Stack(OCAB(d, nhead, ff), n_cab, None)
+        self.decoder = _Stack(OTTB(d, nhead, ff), n_ttb, nn.InstanceNorm1d(d, affine=True))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, tgt, val):
+        bs, c, h, w = src.shape
+        m = src.flatten(2).permute(2, 0, 1)
+        t = tgt.flatten(2).permute(2, 0, 1)
+        v = val.flatten(2).permute(2, 0, 1)
+        for layer in self.encoder.layers:
+            m = layer(m)
+        for layer in self.decoder.layers:
+            t = layer(t, m, v)
+        return self.decoder.norm(t.permute(1, 2, 0)).reshape(bs, c, h, w)
+
+
+class OSourceEncoder(nn.Module):
+    def __init__(self, image_nc, ngf, img_f, layers, norm):
+        super(OSourceEncoder, self).__init__()
+        self.encoder_layer = layers
+        self.block0 = OEncoderBlockOptimized(image_nc, ngf, norm)
+        mult = 1
+        for i in range(layers - 1):
+            prev, mult = mult, min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder%d' % i, OEncoderBlock(ngf * prev, ngf * mult, norm))
+
+    def forward(self, x):
+        x = self.block0(x)
+        for i in range(self.encoder_layer - 1):
+            x = getattr(self, 'encoder%d' % i)(x)
+        return x
+
+
+class ODPTNGenerator(nn.Module):
+    """networks.py:165-275"""
+
+    def __init__(self, image_nc=3, pose_nc=18, ngf=64, img_f=256, layers=3, norm='instance', output_nc=3, num_blocks=3,
+                 nhead=2, num_CABs=2, num_TTBs=2):
+        super(ODPTNGenerator, self).__init__()
+        self.layers, self.num_blocks = layers, num_blocks
+        self.block0 = OEncoderBlockOptimized(2 * pose_nc + image_nc, ngf, norm)
+        mult = 1
+        for i in range(layers - 1):
+            prev, mult = mult, min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder%d' % i, OEncoderBlock(ngf * prev, ngf * mult, norm))
+        for i in range(num_blocks):
+            setattr(self, 'mblock%d' % i, OResBlock(ngf * mult, ngf * mult, ngf * mult, norm))
+        self.PTM = OPTM(ngf * mult, nhead, num_CABs, num_TTBs, ngf * mult)
+        self.source_encoder = OSourceEncoder(image_nc, ngf, img_f, layers, norm)
+        for i in range(layers):
+            prev = mult
+            mult = min(2 ** (layers - i - 2), img_f // ngf) if i != layers - 1 else 1
+            setattr(self, 'decoder%d' % i, OResBlockDecoder(ngf * prev, ngf * mult, ngf * mult, norm))
+        self.outconv = OOutput(ngf, output_nc, 3)
+
+    def _encode(self, x):
+        x = self.block0(x)
+        for i in range(self.layers - 1):
+            x = getattr(self, 'encoder%d' % i)(x)
+        for i in range(self.num_blocks):
+            x = getattr(self, 'mblock%d' % i)(x)
+        return x
+
+    def _decode(self, f):
+        for i in range(self.layers):
+            f = getattr(self, 'decoder%d' % i)(f)
+        return self.outconv(f)
+
+    def forward(self, source, source_B, target_B, is_train=True):
+        F_s_s = self._encode(torch.cat((source, source_B, source_B), 1))
+        F_s_t = self._encode(torch.cat((source, source_B, target_B), 1))
+        F_s_t = self.PTM(F_s_s, F_s_t, self.source_encoder(source))
+        out_s = self._decode(F_s_s) if is_train else None
+        return self._decode(F_s_t), out_s
+
+
 # ---- PoseGenerator1, networks.py:639-738 ------------------------------------------------------------------
 class OPoseGenerator1(nn.Module):
     def __init__(self, ngf=64, pose_nc=18, img_f=256, layers=3, norm='instance', output_nc=3, nhead=2, num_CABs=2,

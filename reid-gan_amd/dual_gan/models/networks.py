@@ -30,9 +30,12 @@ def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='
                               affine, nhead, num_CABs, num_TTBs)
     elif opt.model_gen == 'AE':
         netG = AEGenerator(image_nc, ngf, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc, num_blocks)
-    elif opt.model_gen in ('DPTN', 'DEC', 'FD', 'PoseAE'):
-        raise NotImplementedError("generator '%s' is not built yet on the HIP path ('Pose' — the joint training step — and "
-                                  "'AE' are)" % opt.model_gen)
+    elif opt.model_gen == 'DPTN':
+        netG = DPTNGenerator(image_nc, pose_nc, ngf, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc,
+                             num_blocks, affine, nhead, num_CABs, num_TTBs)
+    elif opt.model_gen in ('DEC', 'FD', 'PoseAE'):
+        raise NotImplementedError("generator '%s' is not built on the HIP path ('Pose' — the joint training step —, 'AE' and "
+                                  "'DPTN' are)" % opt.model_gen)
     else:
         raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
     return init_net(netG, opt.init_type)
@@ -157,6 +160,149 @@ class AEGenerator(RGModule):
 
     def forward_dec(self, feature):
         return self._sub("dec", feature, self._dec())
+
+
+class SourceEncoder(RGModule):
+    """Source Image Encoder En_s (networks.py:54-101)."""
+
+    def __init__(self, image_nc, ngf=64, img_f=1024, encoder_layer=3, norm='batch', activation='ReLU', use_spect=True,
+                 use_coord=False):
+        super(SourceEncoder, self).__init__()
+        self.encoder_layer = encoder_layer
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        self.block0 = EncoderBlockOptimized(image_nc, ngf, norm_layer, nonlinearity, use_spect, use_coord)
+        mult = 1
+        for i in range(encoder_layer - 1):
+            mult_prev = mult
+            mult = min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder' + str(i), EncoderBlock(ngf * mult_prev, ngf * mult, norm_layer, nonlinearity, use_spect,
+                                                           use_coord))
+
+    def _mods(self):
+        return [self.block0] + [getattr(self, 'encoder' + str(i)) for i in range(self.encoder_layer - 1)]
+
+    def tf(self, tape, x):
+        for m in self._mods():
+            x = m.tf(tape, x)
+        return x
+
+    def tb(self, tape, dy, need_dx=True):
+        mods = self._mods()
+        for i in range(len(mods) - 1, -1, -1):
+            dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
+        return dy
+
+
+class DPTNGenerator(RGModule):
+    """Dual-task Pose Transformer Network generator (networks.py:165-275): a source->source and a source->target branch
+    through SHARED encoder / decoder weights, coupled by the PTM.  Both branches run as ONE 2B batch through the shared
+    blocks (instance norm and convolutions are per-sample, so this equals the reference's two sequential passes)."""
+
+    def __init__(self, image_nc, pose_nc, ngf=64, img_f=256, layers=3, norm='batch', activation='ReLU', use_spect=True,
+                 use_coord=False, output_nc=3, num_blocks=3, affine=True, nhead=2, num_CABs=2, num_TTBs=2):
+        super(DPTNGenerator, self).__init__()
+        if norm != 'instance':
+            raise NotImplementedError("DPTNGenerator batches its two branches, which needs per-sample normalisation "
+                                      "(--norm instance, the training default)")
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        input_nc = 2 * pose_nc + image_nc
+        self.block0 = EncoderBlockOptimized(input_nc, ngf, norm_layer, nonlinearity, use_spect, use_coord)
+        mult = 1
+        for i in range(self.layers - 1):
+            mult_prev = mult
+            mult = min(2 ** (i + 1), img_f // ngf)
+            setattr(self, 'encoder' + str(i), EncoderBlock(ngf * mult_prev, ngf * mult, norm_layer, nonlinearity, use_spect,
+                                                           use_coord))
+        self.num_blocks = num_blocks
+        for i in range(num_blocks):
+            setattr(self, 'mblock' + str(i), ResBlock(ngf * mult, ngf * mult, norm_layer=norm_layer, nonlinearity=nonlinearity,
+                                                      use_spect=use_spect, use_coord=use_coord))
+        self.PTM = PTM(d_model=ngf * mult, nhead=nhead, num_CABs=num_CABs, num_TTBs=num_TTBs, dim_feedforward=ngf * mult,
+                       activation="LeakyReLU", affine=affine, norm=norm)
+        self.source_encoder = SourceEncoder(image_nc, ngf, img_f, layers, norm, activation, use_spect, use_coord)
+        for i in range(self.layers):
+            mult_prev = mult
+            mult = min(2 ** (self.layers - i - 2), img_f // ngf) if i != self.layers - 1 else 1
+            setattr(self, 'decoder' + str(i), ResBlockDecoder(ngf * mult_prev, ngf * mult, ngf * mult, norm_layer, nonlinearity,
+                                                              use_spect, use_coord))
+        self.outconv = Output(ngf, output_nc, 3, None, nonlinearity, use_spect, use_coord)
+
+    def forward(self, source, source_B, target_B, is_train=True):
+        self._is_train = bool(is_train)
+        return super(DPTNGenerator, self).forward(source, source_B, target_B)
+
+    def _enc(self):
+        return ([self.block0] + [getattr(self, 'encoder' + str(i)) for i in range(self.layers - 1)] +
+                [getattr(self, 'mblock' + str(i)) for i in range(self.num_blocks)])
+
+    def _dec(self):
+        return [getattr(self, 'decoder' + str(i)) for i in range(self.layers)] + [self.outconv]
+
+    def tf(self, tape, source, source_B, target_B):
+        is_train = getattr(self, "_is_train", True)
+        B = source.shape[0]
+        x = torch.cat((ops.cat_channels([source, source_B, source_B]), ops.cat_channels([source, source_B, target_B])), 0)
+        for m in self._enc():
+            x = m.tf(tape, x)
+        F_s_s, F_s_t = x[:B], x[B:]
+        F_s = self.source_encoder.tf(tape, source)
+        F_s_t = self.PTM.tf(tape, F_s_s, F_s_t, F_s)
+        y = torch.cat((F_s_s, F_s_t), 0) if is_train else F_s_t
+        for m in self._dec():
+            y = m.tf(tape, y)
+        tape.push((B, is_train))
+        if is_train:
+            return y[B:], y[:B]                       # (out_image_t, out_image_s)
+        return y, None
+
+    def tb(self, tape, d_t, d_s=None, need_dx=True):
+        B, is_train = tape.pop()
+        dev = (d_t if d_t is not None else d_s).device
+        if is_train:
+            zeros = None
+            if d_t is None or d_s is None:
+                ref = d_t if d_t is not None else d_s
+                zeros = ops.fill_(torch.empty_like(ref), 0.0)
+            d = torch.cat((d_s if d_s is not None else zeros, d_t if d_t is not None else zeros), 0)
+        else:
+            d = d_t
+        for m in reversed(self._dec()):
+            d = m.tb(tape, d)
+        if is_train:
+            d_ss, d_st = d[:B].contiguous(), d[B:].contiguous()
+        else:
+            d_ss, d_st = None, d
+        d_src, d_tgt, d_val = self.PTM.tb(tape, d_st)
+        d_ss = d_src if d_ss is None else ops.axpby(d_ss, d_src, 1.0, 1.0, out=d_ss)
+        ni = tape.needs_input
+        need_img = need_dx and (ni is None or bool(ni[0]))
+        d_source = self.source_encoder.tb(tape, d_val, need_dx=need_img)
+        d = torch.cat((d_ss, d_tgt), 0)
+        mods = self._enc()
+        need_any = need_dx and (ni is None or any(bool(v) for v in ni))
+        for i in range(len(mods) - 1, -1, -1):
+            d = mods[i].tb(tape, d, need_dx=(need_any or i > 0))
+        if not need_any:
+            return None, None, None
+        # channels of the stacked inputs: [source | source_B | source_B] and [source | source_B | target_B]
+        return _dptn_input_grads(d, B, d_source)
+
+
+def _dptn_input_grads(d, B, d_source):
+    """split the gradient of the two stacked DPTN inputs back onto (source, source_B, target_B)"""
+    c_img = 3 if d_source is None else d_source.shape[1]
+    c_pose = (d.shape[1] - c_img) // 2
+    top, bot = d[:B], d[B:]
+    g_src = ops.add(ops.slice_channels(top, 0, c_img), ops.slice_channels(bot, 0, c_img))
+    if d_source is not None:
+        g_src = ops.add(g_src, d_source)
+    g_sb = ops.add(ops.add(ops.slice_channels(top, c_img, c_img + c_pose), ops.slice_channels(top, c_img + c_pose, c_img + 2 * c_pose)),
+                   ops.slice_channels(bot, c_img, c_img + c_pose))
+    g_tb = ops.slice_channels(bot, c_img + c_pose, c_img + 2 * c_pose)
+    return g_src, g_sb, g_tb
 
 
 class PoseGenerator1(RGModule):

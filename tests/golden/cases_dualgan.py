@@ -63,3 +63,13 @@ def aegen_case():
     _perturb(net, 76)
     net.train()
     return net, D.synth_dualgan_inputs(2, 64, 32, seed=77)['Xs']
+
+
+def dptn_case():
+    torch.manual_seed(85)
+    net = D.o_init_weights(D.ODPTNGenerator(3, 18, 64, 256, 3, 'instance', 3, 3, 2, 2, 2))
+    _perturb(net, 86)
+    net.train()
+    a = D.synth_dualgan_inputs(2, 64, 32, seed=87)
+    b = D.synth_dualgan_inputs(2, 64, 32, seed=88)
+    return net, (a['Xs'], a['Ps'], b['Ps'])

@@ -114,6 +114,27 @@ def main():
     out["aegen_fwd"], out["aegen_fwd_stats"] = sub(yr)
     out["aegen_enc"], out["aegen_enc_stats"] = sub(rn.forward_enc(x))
 
+    print("DPTNGenerator")
+    on, (xs, ps, pt) = C.dptn_case()
+    rn = ref_net.DPTNGenerator(3, 18, 64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3, True, 2, 2, 2)
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    (to, so), (tr, sr) = on(xs, ps, pt), rn(xs, ps, pt)
+    check(to, tr, "dptn_fwd_t")
+    check(so, sr, "dptn_fwd_s")
+    g = torch.Generator().manual_seed(6)
+    dt, ds = torch.randn(tr.shape, generator=g), torch.randn(sr.shape, generator=g)
+    ((to * dt).sum() + (so * ds).sum()).backward()
+    ((tr * dt).sum() + (sr * ds).sum()).backward()
+    out["dptn_fwd_t"], out["dptn_fwd_t_stats"] = sub(tr)
+    out["dptn_fwd_s"], out["dptn_fwd_s_stats"] = sub(sr)
+    pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+    for k in ["block0.model.0.weight", "mblock1.conv2.weight", "PTM.decoder.layers.0.multihead_attn.in_proj_weight",
+              "source_encoder.encoder1.model.2.weight", "decoder1.model.2.weight", "outconv.conv1.weight"]:
+        check(po[k].grad, pr[k].grad, "dptn grad " + k, 2e-4)
+        out["dptn_g_" + k], _ = sub(pr[k].grad)
+    check(on(xs, ps, pt, False)[0], rn(xs, ps, pt, False)[0], "dptn_fwd_t (is_train=False)")
+
     print("ResDiscriminator (spectral norm)")
     on, x = C.resdisc_case()
     rn = ref_net.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)

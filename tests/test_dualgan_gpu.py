@@ -296,3 +296,32 @@ def test_aegenerator_and_gan_step(dev):
     assert abs(errs["G"] - omodel.loss_G.item()) <= 1e-3 * abs(omodel.loss_G.item()), (errs, omodel.loss_G.item())
     _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params")
     _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params")
+
+
+def test_dptn_generator(dev):
+    """DPTNGenerator (both branches batched through the shared blocks) against the oracle (== reference): both outputs,
+    all parameter gradients (shared weights receive both branches' contributions), the image gradient, and the
+    inference form (is_train=False)."""
+    from dual_gan.models import networks as N
+    from tests.golden import cases_dualgan as C
+    from tests.golden.cases import sub
+    on, (xs, ps, pt) = C.dptn_case()
+    rg = _load(N.DPTNGenerator(3, 18, 64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3, True, 2, 2, 2), on, dev)
+    rg.train()
+    xo, xd = xs.clone().requires_grad_(True), xs.to(dev).requires_grad_(True)
+    (to, so), (tr, sr) = on(xo, ps, pt), rg(xd, ps.to(dev), pt.to(dev))
+    _check(tr, to, 1e-3, "dptn out_t")
+    _check(sr, so, 1e-3, "dptn out_s")
+    ref = GOLD["dptn_fwd_t"]
+    got = np.asarray(sub(tr.detach().cpu())[0], dtype=np.float64).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+    g = torch.Generator().manual_seed(6)
+    dt, ds = torch.randn(to.shape, generator=g), torch.randn(so.shape, generator=g)
+    ((to * dt).sum() + (so * ds).sum()).backward()
+    torch.autograd.backward([tr, sr], [dt.to(dev), ds.to(dev)])
+    _check_l2(xd.grad, xo.grad, 5e-3, "dptn d source")
+    _check_grads(rg, on, 5e-3, "dptn grads", tol_tensor=2e-2)
+    with torch.no_grad():
+        ti, si = rg(xs.to(dev), ps.to(dev), pt.to(dev), False)
+    assert si is None
+    _check(ti, on(xs, ps, pt, False)[0], 1e-3, "dptn inference out_t")

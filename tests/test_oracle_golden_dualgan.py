@@ -92,3 +92,17 @@ def test_aegenerator():
     s, st = sub(net.forward_enc(x))
     _cmp(s, "aegen_enc")
     _cmp(st, "aegen_enc_stats")
+
+
+def test_dptn_generator():
+    net, (xs, ps, pt) = C.dptn_case()
+    t, s_ = net(xs, ps, pt)
+    _cmp(sub(t)[0], "dptn_fwd_t")
+    _cmp(sub(s_)[0], "dptn_fwd_s")
+    g = torch.Generator().manual_seed(6)
+    dt, ds = torch.randn(t.shape, generator=g), torch.randn(s_.shape, generator=g)
+    ((t * dt).sum() + (s_ * ds).sum()).backward()
+    params = dict(net.named_parameters())
+    for key in GOLD.files:
+        if key.startswith("dptn_g_"):
+            _cmp(sub(params[key[len("dptn_g_"):]].grad)[0], key, 2e-4)
