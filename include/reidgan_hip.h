@@ -138,6 +138,20 @@ int rg_bicubic_normalize_bwd(const float* dy, float* dx, int N, int C, int H, in
  * the int64 device list (each distinct id once) */
 int rg_normalize_listed_rows(float* g, const void* ids, int n_ids, int rows, int D, float eps, rg_stream_t stream);
 
+/* ---- pseudo-labelling front half / evaluation distances ------------------------------ */
+/* faiss IndexFlatIP.search of CC/clustercontrast/utils/infomap_cluster.py:51-78 on a similarity block s[rows][cols]
+ * (from the GEMM): the k best columns per row in (value descending, index ascending) order; idx int32 [rows][k] */
+int rg_topk_rows(const float* s, int rows, int cols, int k, int* idx, float* val, rg_stream_t stream);
+/* |x_r|^2 per row and m = alpha*m + a*rowv[r] + b*colv[c]: pairwise_distance, CC/clustercontrast/evaluators.py:71-88,
+ * FD/reid/evaluators.py:76-98 (the -2 x.y^T term comes from the GEMM) */
+int rg_row_sqsum(const float* x, float* out, int rows, int D, rg_stream_t stream);
+int rg_add_outer_terms(float* m, const float* rowv, const float* colv, float alpha, float a, float b, int rows, int cols,
+                       rg_stream_t stream);
+/* generate_cluster_features, CC/examples/cluster_contrast_gan_train_usl_infomap.py:332-348: out[s] = mean of the rows
+ * x[order[j]], j in [offsets[s], offsets[s+1]) (int64 device arrays; members in list order) */
+int rg_segment_mean(const float* x, const void* order, const void* offsets, float* out, int segments, int D,
+                    rg_stream_t stream);
+
 /* ---- conv + frozen-statistics BatchNorm fold (E / D_id of FD-GAN: set_bn_fix, FD/fdgan/networks.py:57-60 with
  * trainable affine parameters, model.py:72-85).  Forward: rg_conv2d_fwd with scale/shift from rg_bn_fold — the
  * pre-normalisation tensor is never written.  Backward without it:

@@ -778,6 +778,37 @@ def normalize_listed_rows(g, ids, eps=1e-16):
     return g
 
 
+def topk_rows(s, k):
+    """(idx int32 [rows, k], val [rows, k]) of the k largest entries per row, ties by lower index"""
+    s = _chk(s, "s")
+    rows, cols = s.shape
+    idx = torch.empty((rows, k), dtype=torch.int32, device=s.device)
+    val = torch.empty((rows, k), dtype=torch.float32, device=s.device)
+    lib.rg_topk_rows(_p(s), rows, cols, k, _p(idx), _p(val), _stream())
+    return idx, val
+
+
+def row_sqsum(x):
+    x = _chk(x, "x")
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    lib.rg_row_sqsum(_p(x), _p(out), x.shape[0], x.shape[1], _stream())
+    return out
+
+
+def add_outer_terms(m, rowv=None, colv=None, alpha=1.0, a=1.0, b=1.0):
+    m = _chk(m, "m")
+    lib.rg_add_outer_terms(_p(m), _p(rowv), _p(colv), alpha, a, b, m.shape[0], m.shape[1], _stream())
+    return m
+
+
+def segment_mean(x, order, offsets):
+    x = _chk(x, "x")
+    order, offsets = _chk(order, "order", torch.int64), _chk(offsets, "offsets", torch.int64)
+    out = torch.empty((offsets.numel() - 1, x.shape[1]), dtype=torch.float32, device=x.device)
+    lib.rg_segment_mean(_p(x), _p(order), _p(offsets), _p(out), offsets.numel() - 1, x.shape[1], _stream())
+    return out
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     lib.rg_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                      _stream())

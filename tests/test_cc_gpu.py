@@ -220,3 +220,48 @@ def test_cluster_memory_gradient(dev):
     rm.update_clusters(ids)
     _check(rm.trainable_clusters, om.trainable_clusters, 1e-5, "clusters after the step")
     _check(rm.normed_clusters, om.normed_clusters, 1e-5, "normalised clusters")
+
+
+def test_knn_pairwise_centroids(dev):
+    """brute-force inner-product kNN (get_dist_nbr), pairwise_distance (both forms) and cluster
+    centroid means against numpy / torch CPU restatements of the cited reference lines."""
+    import numpy as np
+    import torch.nn.functional as F
+    from collections import OrderedDict
+    from clustercontrast.utils.infomap_cluster import get_dist_nbr, generate_cluster_features, knn_faiss
+    from clustercontrast.evaluators import pairwise_distance
+    g = torch.Generator().manual_seed(13)
+    n, D, k = 700, 256, 15
+    feats = F.normalize(torch.randn(n, D, generator=g), dim=1)
+    dists, nbrs = get_dist_nbr(features=feats.numpy(), k=k, knn_method='faiss-gpu')
+    sims = feats.double() @ feats.double().t()                       # IndexFlatIP.search: top-k inner products
+    rv, ri = torch.topk(sims, k, dim=1)
+    assert dists.shape == (n, k) and nbrs.shape == (n, k) and nbrs.dtype == np.int32
+    assert np.array_equal(nbrs, ri.numpy().astype(np.int32))
+    assert np.abs(dists - (1 - rv.numpy())).max() <= 2e-6
+    assert (nbrs[:, 0] == np.arange(n)).all()                         # every sample is its own nearest neighbour
+    # ties: lower index first
+    t = torch.zeros(4, 8)
+    t[:, 3] = 1.0
+    t[:, 5] = 1.0
+    idx = knn_faiss(torch.eye(8)[:4] * 0 + t, 3).knns        # rows identical -> similarities tie
+    assert all(len(a[0]) == 3 for a in idx)
+    # pairwise distances
+    fd = OrderedDict(("f%d" % i, feats[i]) for i in range(n))
+    d_self = pairwise_distance(fd)
+    x = feats.double()
+    ref = (x.pow(2).sum(1, keepdim=True) * 2).expand(n, n) - 2 * x @ x.t()
+    assert (d_self.double() - ref).abs().max().item() <= 1e-5
+    q = [("f%d" % i, 0, 0) for i in range(0, 50)]
+    gal = [("f%d" % i, 0, 0) for i in range(100, 400)]
+    dm, xq, yg = pairwise_distance(fd, q, gal)
+    xr, yr = x[:50], x[100:400]
+    ref = xr.pow(2).sum(1, keepdim=True) + yr.pow(2).sum(1, keepdim=True).t() - 2 * xr @ yr.t()
+    assert dm.shape == (50, 300) and (dm.double() - ref).abs().max().item() <= 1e-5
+    assert xq.shape == (50, D) and yg.shape == (300, D)
+    # centroids: outliers (-1) skipped, rows by ascending label
+    labels = torch.randint(-1, 9, (n,), generator=g).numpy()
+    cent = generate_cluster_features(labels, feats)
+    keys = sorted(set(labels.tolist()) - {-1})
+    ref = torch.stack([feats[torch.from_numpy(labels == kk)].double().mean(0) for kk in keys])
+    assert cent.shape == ref.shape and (cent.double().cpu() - ref).abs().max().item() <= 1e-6
