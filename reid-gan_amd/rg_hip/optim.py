@@ -86,28 +86,51 @@ class _FlatOptimizer(Optimizer):
             self._arena = Arena(ps)
         self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
 
-    def _adopt_foreign_grads(self):
-        for p in self._arena.params:        # gradients set by hand / by stock autograd: copy into the arena
-            if p.grad is not None and p.grad.data_ptr() != p._rg_grad.data_ptr():
-                p._rg_grad.copy_(p.grad)
-                p.grad = p._rg_grad
+    def _have(self):
+        """indices of the parameters that received a gradient; gradients set by hand / by stock autograd are copied into
+        the arena first.  (`p.grad is view` is an identity test on the Python wrapper the tape assigned — no data_ptr calls:
+        this loop runs while the GPU queue is nearly empty, so its host time is GPU idle time.)"""
+        a = self._arena
+        views = getattr(a, "_views", None)
+        if views is None:
+            views = a._views = [p._rg_grad for p in a.params]
+        have = []
+        for i, p in enumerate(a.params):
+            g = p.grad
+            if g is None:
+                continue
+            if g is not views[i]:
+                if g.data_ptr() != views[i].data_ptr():
+                    views[i].copy_(g)
+                p.grad = views[i]
+            have.append(i)
+        return have
 
     def _segments(self, key_of):
-        """maximal runs of consecutive parameters that have a gradient and share key_of(i): (a0, a1, [i...])"""
+        """maximal runs of consecutive parameters that have a gradient and share key_of(i): [a0, a1, [i...], key].
+        The run structure is cached: it only depends on WHICH parameters have a gradient and on the per-group
+        hyper-parameters, both normally identical from step to step."""
         a = self._arena
-        segs, cur = [], None
-        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
-            end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
-            if p.grad is None:
-                cur = None
-                continue
-            k = key_of(i)
-            if cur is not None and cur[3] == k:
-                cur[1] = end
+        have = self._have()
+        gkeys = tuple(key_of(None, gi) for gi in range(len(self.param_groups)))
+        sig = (tuple(have), gkeys)
+        cache = getattr(self, "_seg_cache", None)
+        if cache is not None and cache[0] == sig and self._uniform_state(cache[1]):
+            return cache[1]
+        ends = getattr(a, "_ends", None)
+        if ends is None:
+            ends = a._ends = [o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN for p, o in zip(a.params, a.offsets)]
+        segs, cur, last = [], None, -2
+        for i in have:
+            k = key_of(i, self._group_of[i])
+            if cur is not None and last == i - 1 and cur[3] == k:
+                cur[1] = ends[i]
                 cur[2].append(i)
             else:
-                cur = [o, end, [i], k]
+                cur = [a.offsets[i], ends[i], [i], k]
                 segs.append(cur)
+            last = i
+        self._seg_cache = (sig, segs)
         return segs
 
     def zero_grad(self, set_to_none=True):
@@ -125,20 +148,29 @@ class Adam(_FlatOptimizer):
         self._v = torch.zeros_like(self._arena.flat)
         self._steps = [0] * len(self._arena.params)
 
+    def _uniform_state(self, segs):
+        """cached runs stay valid while every member of a run still has the run's step count"""
+        st = self._steps
+        return all(st[m[0]] == st[m[-1]] for _, _, m, _ in segs)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        self._adopt_foreign_grads()
         a, groups = self._arena, self.param_groups
 
-        def key_of(i):
-            g = groups[self._group_of[i]]
-            return (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps[i])
-        for a0, a1, members, (lr, b1, b2, eps, wd, st) in self._segments(key_of):
+        def key_of(i, gi):
+            g = groups[gi]
+            base = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
+            return base if i is None else base + (self._steps[i],)
+        for seg in self._segments(key_of):
+            a0, a1, members, key = seg
+            lr, b1, b2, eps, wd = key[:5]
+            st = self._steps[members[0]]
             ops.adam_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._m[a0:a1], self._v[a0:a1], lr, b1, b2, eps, wd,
                           st + 1, self.grad_scale)
             for i in members:
-                self._steps[i] += 1
+                self._steps[i] = st + 1
+            seg[3] = key[:5] + (st + 1,)
         a.epoch += 1                  # invalidates cached filter re-layouts of THIS arena's layers
         return loss
 
@@ -154,18 +186,27 @@ class SGD(_FlatOptimizer):
         self._buf = torch.zeros_like(self._arena.flat)
         self._started = [False] * len(self._arena.params)
 
+    def _uniform_state(self, segs):
+        st = self._started
+        return all(st[m[0]] == st[m[-1]] for _, _, m, _ in segs)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        self._adopt_foreign_grads()
         a, groups = self._arena, self.param_groups
 
-        def key_of(i):
-            g = groups[self._group_of[i]]
-            return (g["lr"], g["momentum"], g["weight_decay"], self._started[i])
-        for a0, a1, members, (lr, mom, wd, started) in self._segments(key_of):
+        def key_of(i, gi):
+            g = groups[gi]
+            base = (g["lr"], g["momentum"], g["weight_decay"])
+            return base if i is None else base + (self._started[i],)
+        for seg in self._segments(key_of):
+            a0, a1, members, key = seg
+            lr, mom, wd = key[:3]
+            started = self._started[members[0]]
             ops.sgd_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._buf[a0:a1], lr, mom, wd, not started, self.grad_scale)
-            for i in members:
-                self._started[i] = True
+            if not started:
+                for i in members:
+                    self._started[i] = True
+            seg[3] = key[:3] + (True,)
         a.epoch += 1
         return loss
