@@ -19,7 +19,7 @@ from rg_hip import nn as rnn
 from rg_hip import ops
 from rg_hip.ops import ACT_LEAKY, ACT_NONE, ACT_TANH
 from rg_hip.parallel import DataParallel
-from rg_hip.tape import RGModule
+from rg_hip.tape import RGModule, _param_list
 
 
 ######################################################################################
@@ -123,7 +123,7 @@ def _freeze(*args):
     """freeze the network for forward process"""
     for module in args:
         if module:
-            for p in module.parameters():
+            for p in _param_list(module):
                 p.requires_grad = False
 
 
@@ -131,7 +131,7 @@ def _unfreeze(*args):
     """ unfreeze the network for parameter update"""
     for module in args:
         if module:
-            for p in module.parameters():
+            for p in _param_list(module):
                 p.requires_grad = True
 
 

@@ -107,11 +107,27 @@ class _NetFn(torch.autograd.Function):
         return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + tuple(grads)
 
 
+def _param_list(net):
+    """list(net.parameters()), built once per network: walking the module tree on every call costs milliseconds per
+    step on the small-kernel networks, whose steps are host-bound.  The tree of a built network does not change; call
+    invalidate_param_cache(net) after surgery on its sub-modules."""
+    plist = net.__dict__.get("_rg_plist")
+    if plist is None:
+        plist = list(net.parameters())
+        net.__dict__["_rg_plist"] = plist
+    return plist
+
+
+def invalidate_param_cache(net):
+    for m in net.modules():
+        m.__dict__.pop("_rg_plist", None)
+
+
 def run(net, *xs):
     """Execute `net` as one autograd node (or plainly when no gradient is required)."""
     grad_on = torch.is_grad_enabled()
     frozen = getattr(net, "_rg_frozen", False)
-    params = [] if (frozen or not grad_on) else [p for p in net.parameters() if p.requires_grad]
+    params = [] if (frozen or not grad_on) else [p for p in _param_list(net) if p.requires_grad]
     need_graph = grad_on and (len(params) > 0 or any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs))
     if not need_graph:
         return net.tf(Tape(param_grad=False, record=False), *xs)

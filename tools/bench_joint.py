@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of 3 steps")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -95,9 +96,21 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.cprofile:
+        import cProfile, pstats, io
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(3):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(32)
+        print(st.getvalue()[:7000], file=sys.stderr)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_host = (time.perf_counter() - t0) / args.steps        # host enqueue time (no sync inside the loop)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     ops.profile_reset()
@@ -107,7 +120,7 @@ def main():
     torch.cuda.synchronize()
     ops.profile_enable(False)
     fam = ops.profile_collect()
-    out = {"workload": args.workload, "batch_crops": B, "ms_per_step": round(1e3 * dt, 3), "images_per_s": round(B / dt, 1),
+    out = {"workload": args.workload, "batch_crops": B, "ms_per_step": round(1e3 * dt, 3), "host_enqueue_ms_per_step": round(1e3 * t_host, 3), "images_per_s": round(B / dt, 1),
            "loss": round(float(loss), 5), "gflop_per_crop_algorithmic": gflop_per_crop,
            "step_tflops": round(gflop_per_crop * B / dt / 1e3, 2),
            "by_family": {k: {"ms_per_step": round(v["ms"] / args.profile_steps, 3), "launches": v["calls"] // args.profile_steps,
