@@ -1303,7 +1303,18 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
         else if (K % 16 == 0) mode = 1;
         if (mode) p.w = wk;
     }
-    GemmPlan pl = plan_gemm(p.M, one_class ? ng_max : ng_max * SH * SW, kg_max, one_class);
+    // strided classes: only classes that have filter taps do MFMA work (a 1x1 / stride-2 layer has ONE such class, the
+    // others only zero-fill), and their reductions differ — plan on the columns that carry work and their mean depth
+    int64_t ng_eff = 0;
+    double kw_sum = 0.0;
+    for (int i = 0; i < SH * SW; ++i)
+        if (dp.cls[i].Kgc > 0) {
+            ng_eff += dp.cls[i].Ngc;
+            kw_sum += (double)dp.cls[i].Ngc * dp.cls[i].Kgc;
+        }
+    const int64_t kg_eff = ng_eff > 0 ? (int64_t)(kw_sum / (double)ng_eff) : kg_max;
+    GemmPlan pl = one_class ? plan_gemm(p.M, ng_max, kg_max, true) : plan_gemm(p.M, ng_eff > 0 ? ng_eff : ng_max, kg_eff, false);
+    if (!one_class) pl.ktiles_per_split = 1 << 30;       // planned on the MEAN depth: every class runs its full reduction
     const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
     if (need > workspace_bytes || (need && !workspace)) {
         pl.splits = 1;
