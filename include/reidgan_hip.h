@@ -77,6 +77,9 @@ int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float*
                     const float* shift, const float* residual, int act, float slope, const float* relu_mask,
                     void* workspace, size_t workspace_bytes, rg_stream_t stream);
 int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, rg_stream_t stream);
+/* development knob: pin the fwd/dgrad planner's tile (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x256) and split-K count;
+ * (-1, -1) releases it (same effect as the RG_CONV_FORCE="tile,splits" environment variable) */
+int rg_conv_set_force(int tile, int splits);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,

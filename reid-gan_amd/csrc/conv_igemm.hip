@@ -1095,16 +1095,16 @@ struct GemmPlan {
 };
 
 // Development override: RG_CONV_FORCE="tile,splits" (tile 0..3 or -1, splits >= 1 or -1) pins the choice.
+static int g_force_tile = -2, g_force_splits = -2;
 static void force_override(int* tile, int* splits) {
-    static int f_tile = -2, f_splits = -2;
-    if (f_tile == -2) {
-        f_tile = -1;
-        f_splits = -1;
+    if (g_force_tile == -2) {
+        g_force_tile = -1;
+        g_force_splits = -1;
         const char* e = getenv("RG_CONV_FORCE");
-        if (e) sscanf(e, "%d,%d", &f_tile, &f_splits);
+        if (e) sscanf(e, "%d,%d", &g_force_tile, &g_force_splits);
     }
-    if (f_tile >= 0 && f_tile <= 3) *tile = f_tile;
-    if (f_splits >= 1) *splits = f_splits;
+    if (g_force_tile >= 0 && g_force_tile <= 3) *tile = g_force_tile;
+    if (g_force_splits >= 1) *splits = g_force_splits;
 }
 
 // Tile + split-K choice for the fwd / dgrad GEMMs (M x Ng outputs, Kg reduction), allow_split = single-class output.
@@ -1233,6 +1233,13 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
                            p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
     }
     return rg::check_launch("rg_conv2d_fwd");
+}
+
+// development knob (tools/sweep_tiles.py): pin the planner's tile / split choice at run time; (-1, -1) releases it
+extern "C" int rg_conv_set_force(int tile, int splits) {
+    g_force_tile = tile;
+    g_force_splits = splits;
+    return RG_OK;
 }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
