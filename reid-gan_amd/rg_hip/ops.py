@@ -60,6 +60,20 @@ class _Workspace(object):
 _ws = _Workspace()
 
 
+_ws_sizes = {}
+
+
+def _ws_query(fn, *dims):
+    """workspace size queries are pure functions of the geometry: ask the library once per shape (the small-kernel
+    steps are host-bound; this removes a third of their ctypes calls).  The planner force knob changes the answer, so
+    rg_conv_set_force users call _ws_sizes.clear()."""
+    key = (fn,) + dims
+    v = _ws_sizes.get(key)
+    if v is None:
+        v = _ws_sizes[key] = getattr(lib, fn)(*dims)
+    return v
+
+
 def workspace(nbytes, device):
     return _ws.get(nbytes, device)
 
@@ -98,7 +112,7 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
         raise ValueError("conv2d_fwd: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
     if w_krsc is None and KH * KW > 1 and C % 16 == 0:
         w_krsc = weights_to_krsc(w)
-    nbytes = lib.rg_conv2d_fwd_workspace(N, C, K, KH, KW, P, Q)
+    nbytes = _ws_query("rg_conv2d_fwd_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device) if nbytes else None
     lib.rg_conv2d_fwd(_p(x), _p(w), _p(w_krsc), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
                       _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
@@ -123,7 +137,7 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
         raise ValueError("conv2d_dgrad: residual shape mismatch")
     if w_krsc is None and KH * KW > 1 and C % 4 == 0:
         w_krsc = weights_to_krsc(w)
-    nbytes = lib.rg_conv2d_dgrad_workspace(N, C, H, W, K, KH, KW, sh, sw)
+    nbytes = _ws_query("rg_conv2d_dgrad_workspace", N, C, H, W, K, KH, KW, sh, sw)
     ws = workspace(nbytes, dy.device) if nbytes else None
     relu_mask = _chk(relu_mask, "relu_mask")
     if relu_mask is not None and relu_mask.shape != dx.shape:
@@ -217,7 +231,7 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
     sh, sw = _pair(stride)
     ph, pw = _pair(padding)
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
-    nbytes = lib.rg_conv2d_wgrad_workspace(N, C, K, KH, KW, P, Q)
+    nbytes = _ws_query("rg_conv2d_wgrad_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device)
     lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
                         _stream())
@@ -260,7 +274,7 @@ def bn_stats(x, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     N, C, HW = _nchw(x)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = workspace(lib.rg_bn_workspace(N, C, HW), x.device)
+    ws = workspace(_ws_query("rg_bn_workspace", N, C, HW), x.device)
     lib.rg_bn_stats(_p(x), _p(mean), _p(invstd), _p(running_mean), _p(running_var), N, C, HW, eps, momentum, _p(ws),
                     ws.numel(), _stream())
     return mean, invstd
@@ -283,7 +297,7 @@ def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT
     sum_dy = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     sum_dy_xhat = out_sum_dy_xhat if out_sum_dy_xhat is not None else \
         torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = workspace(lib.rg_bn_workspace(N, C, HW), x.device)
+    ws = workspace(_ws_query("rg_bn_workspace", N, C, HW), x.device)
     lib.rg_bn_bwd_reduce(_p(x), _p(dy), _p(y_act), _p(mean), _p(stat), _p(sum_dy), _p(sum_dy_xhat), N, C, HW,
                          int(stat_is_var), eps, act, slope, _p(ws), ws.numel(), _stream())
     return sum_dy, sum_dy_xhat
@@ -311,7 +325,7 @@ def bn_eval_bwd(x, dy, y_act, running_mean, running_var, gamma, eps=1e-5, act=AC
     if need_sums:
         s1 = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
         s2 = out_sum_dy_xhat if out_sum_dy_xhat is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
-    ws = workspace(lib.rg_bn_workspace(N, C, HW), dy.device)
+    ws = workspace(_ws_query("rg_bn_workspace", N, C, HW), dy.device)
     lib.rg_bn_eval_bwd(_p(x), _p(dy), _p(y_act), _p(running_mean), _p(running_var), _p(gamma), _p(dx), _p(dres), _p(s1),
                        _p(s2), N, C, HW, eps, act, slope, _p(ws), ws.numel(), _stream())
     return dx, dres, s1, s2
@@ -334,7 +348,7 @@ def act_bwd_sum(dy, y_act, act, slope=0.0, need_g=True, need_sum=True, out_sum=N
     sg = None
     if need_sum:
         sg = out_sum if out_sum is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
-    ws = workspace(lib.rg_bn_workspace(N, C, HW), dy.device)
+    ws = workspace(_ws_query("rg_bn_workspace", N, C, HW), dy.device)
     lib.rg_act_bwd_sum(_p(dy), _p(y_act), _p(g), _p(sg), N, C, HW, act, slope, _p(ws), ws.numel(), _stream())
     return g, sg
 

@@ -36,11 +36,13 @@ for name, cnt, C, H, W, K, k, s, p in shapes:
     wk = ops.weights_to_krsc(w) if k > 1 and C % 4 == 0 else None
     for kind, fn in (("fwd", lambda: ops.conv2d_fwd(x, w, s, p, w_krsc=wk)), ("dgrad", lambda: ops.conv2d_dgrad(dy, w, (H, W), s, p, w_krsc=wk))):
         lib.rg_conv_set_force(-1, -1)
+        ops._ws_sizes.clear()
         base = t(fn)
         best, bcfg = base, "plan"
         for tile in (0, 1, 2):
             for sp in ((1, 2, 4, 8) if (kind == "fwd" or s == 1) else (1,)):
                 lib.rg_conv_set_force(tile, sp)
+                ops._ws_sizes.clear()
                 try:
                     us = t(fn, 4)
                 except Exception:
@@ -48,6 +50,7 @@ for name, cnt, C, H, W, K, k, s, p in shapes:
                 if us < best:
                     best, bcfg = us, "t%d s%d" % (tile, sp)
         lib.rg_conv_set_force(-1, -1)
+        ops._ws_sizes.clear()
         tot[kind][0] += base * cnt; tot[kind][1] += best * cnt
         flag = "  <-- %.0f%%" % (100 * (base - best) / base) if best < 0.93 * base else ""
         print("%-11s x%d %-5s plan %6.1f us  best %6.1f us (%s)%s" % (name, cnt, kind, base, best, bcfg, flag))
