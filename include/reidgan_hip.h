@@ -166,8 +166,14 @@ int rg_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                float* scale, float* shift, float* invstd, int C, rg_stream_t stream);
 int rg_act_bwd_sum(const float* dy, const float* y_act, float* g, float* sum_g, int N, int C, int HW, int act, float slope,
                    void* workspace, size_t workspace_bytes, rg_stream_t stream);
+/* sums either as sum_g[K] (rg_act_bwd_sum) or as slice partials [K][n_slices] of rg_act_bwd_partial, which
+ * rg_bn_fold_wgrad then adds up itself and also writes as dbeta (saves the finalize launch on the critical stream) */
 int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
-                     const float* sum_g, float* dgamma, int K, int M, rg_stream_t stream);
+                     const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma, int K, int M,
+                     rg_stream_t stream);
+int rg_bn_slices(int N, int C, int HW);
+int rg_act_bwd_partial(const float* dy, const float* y_act, float* g, float* part, int N, int C, int HW, int act, float slope,
+                       rg_stream_t stream);
 int rg_scale_rows(const float* w, const float* scale, float* out, int K, int M, rg_stream_t stream);
 
 /* All (conv, frozen BatchNorm) pairs of a network in ONE launch: `table` is a device array of 16 int64 words per pair

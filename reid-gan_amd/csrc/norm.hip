@@ -456,16 +456,24 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 __global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(const float* __restrict__ w, float* __restrict__ g,
                                                             const float* __restrict__ scale, const float* __restrict__ invstd,
                                                             const float* __restrict__ mean, const float* __restrict__ sum_g,
+                                                            const float* __restrict__ part, int S, float* __restrict__ dbeta,
                                                             float* __restrict__ dgamma, int M) {
     __shared__ float red[16];
     const int k = blockIdx.x;
     const float* wr = w + (int64_t)k * M;
     float* gr = g + (int64_t)k * M;
+    float sg = 0.f;
+    if (part) {                       // channel sum of g from the slice partials of rg_act_bwd_partial (fixed order)
+        for (int s = 0; s < S; ++s) sg += part[(int64_t)k * S + s];
+        if (dbeta && threadIdx.x == 0) dbeta[k] = sg;
+    } else if (sum_g) {
+        sg = sum_g[k];
+    }
     if (dgamma) {
         float t = 0.f;
         for (int m = threadIdx.x; m < M; m += 256) t += wr[m] * gr[m];
         t = rg_block_sum(t, red);
-        if (threadIdx.x == 0) dgamma[k] = invstd[k] * (t - mean[k] * sum_g[k]);
+        if (threadIdx.x == 0) dgamma[k] = invstd[k] * (t - mean[k] * sg);
     }
     const float sc = scale[k];
     for (int m = threadIdx.x; m < M; m += 256) gr[m] *= sc;
@@ -682,12 +690,33 @@ extern "C" int rg_act_bwd_sum(const float* dy, const float* y_act, float* g, flo
 }
 
 extern "C" int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
-                                const float* sum_g, float* dgamma, int K, int M, hipStream_t stream) {
+                                const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma, int K,
+                                int M, hipStream_t stream) {
     RG_REQUIRE(w && g && scale && K > 0 && M > 0, "rg_bn_fold_wgrad: bad arguments");
-    RG_REQUIRE(!dgamma || (invstd && running_mean && sum_g), "rg_bn_fold_wgrad: dgamma needs invstd, mean and sum_g");
+    RG_REQUIRE(!dgamma || (invstd && running_mean && (sum_g || partials)), "rg_bn_fold_wgrad: dgamma needs invstd, mean and the sums");
+    RG_REQUIRE(!partials || n_slices > 0, "rg_bn_fold_wgrad: partials need their slice count");
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 12.0 * K * (double)M);
-    hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(K), dim3(256), 0, stream, w, g, scale, invstd, running_mean, sum_g, dgamma, M);
+    hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(K), dim3(256), 0, stream, w, g, scale, invstd, running_mean, sum_g, partials,
+                       n_slices, dbeta, dgamma, M);
     return rg::check_launch("rg_bn_fold_wgrad");
+}
+
+// slice partials only (no finalize launch): part[C][rg_bn_slices(N, C, HW)], consumed by rg_bn_fold_wgrad
+extern "C" int rg_bn_slices(int N, int C, int HW) {
+    int L;
+    return pick_slices(N, C, HW, &L);
+}
+
+extern "C" int rg_act_bwd_partial(const float* dy, const float* y_act, float* g, float* part, int N, int C, int HW, int act,
+                                  float slope, hipStream_t stream) {
+    RG_REQUIRE(dy && part && N > 0 && C > 0 && HW > 0, "rg_act_bwd_partial: bad arguments");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_act_bwd_partial: the activation gradient needs the forward output");
+    int L;
+    const int S = pick_slices(N, C, HW, &L);
+    const double el = (double)N * C * HW;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * el * (1.0 + (act != RG_ACT_NONE ? 1.0 : 0.0) + (g ? 1.0 : 0.0)));
+    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(S, C), dim3(256), 0, stream, dy, y_act, g, part, N, C, HW, L, act, slope, 1);
+    return rg::check_launch("rg_act_bwd_partial");
 }
 
 extern "C" int rg_scale_rows(const float* w, const float* scale, float* out, int K, int M, hipStream_t stream) {

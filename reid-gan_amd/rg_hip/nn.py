@@ -373,20 +373,31 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
     want_w, want_g, want_b = tape.wants(conv.weight), tape.wants(bn.weight), tape.wants(bn.bias)
     need_sum = want_g or want_b
     ob = tape.grad_out(bn.bias) if want_b else None
+    fused_sums = need_sum and (want_w or want_g)          # the wgrad finishing pass adds the slice partials up
+    sg = part = None
     if act != ACT_NONE and not dy_masked:
-        g, sg = ops.act_bwd_sum(dy, y, act, 0.0, need_g=True, need_sum=need_sum, out_sum=ob)
+        if fused_sums:
+            g, part = ops.act_bwd_partial(dy, y, act, 0.0, need_g=True)
+        else:
+            g, sg = ops.act_bwd_sum(dy, y, act, 0.0, need_g=True, need_sum=need_sum, out_sum=ob)
     else:
         g = dy
-        sg = ops.act_bwd_sum(dy, None, ACT_NONE, need_g=False, need_sum=True, out_sum=ob)[1] if need_sum else None
+        if fused_sums:
+            part = ops.act_bwd_partial(dy, None, ACT_NONE, need_g=False)[1]
+        elif need_sum:
+            sg = ops.act_bwd_sum(dy, None, ACT_NONE, need_g=False, need_sum=True, out_sum=ob)[1]
+    dbeta = None
     if want_b:
-        tape.add_grad(bn.bias, sg)
+        dbeta = sg if sg is not None else (ob if ob is not None else torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device))
+        tape.add_grad(bn.bias, dbeta)
     if want_w or want_g:
         w = conv.weight.detach()
         og = tape.grad_out(bn.weight) if want_g else None
         dgamma = (og if og is not None else torch.empty_like(f.scale)) if want_g else None
 
         def finish(G):
-            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma)
+            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
+                              dbeta=dbeta if part is not None else None)
         dw = ops.conv2d_wgrad(x, g, conv.weight.shape, conv.stride, conv.padding,
                               out=tape.grad_out(conv.weight) if want_w else None, side=True, after=finish)
         if want_w:

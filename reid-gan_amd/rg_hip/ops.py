@@ -353,12 +353,26 @@ def act_bwd_sum(dy, y_act, act, slope=0.0, need_g=True, need_sum=True, out_sum=N
     return g, sg
 
 
-def bn_fold_wgrad(w, g, scale, invstd, running_mean, sum_g, dgamma=None):
-    """in place: g (= wgrad of the un-normalised output gradient) *= scale per filter; dgamma from sum(w * g)."""
+def bn_fold_wgrad(w, g, scale, invstd, running_mean, sum_g, dgamma=None, partials=None, dbeta=None):
+    """in place: g (= wgrad of the un-normalised output gradient) *= scale per filter; dgamma from sum(w * g); the channel
+    sums come as sum_g[K] or as slice partials [K, S] (then dbeta is written here too)."""
     K = w.shape[0]
     M = w.numel() // K
-    lib.rg_bn_fold_wgrad(_p(w), _p(g), _p(scale), _p(invstd), _p(running_mean), _p(sum_g), _p(dgamma), K, M, _stream())
+    S = partials.shape[1] if partials is not None else 0
+    lib.rg_bn_fold_wgrad(_p(w), _p(g), _p(scale), _p(invstd), _p(running_mean), _p(sum_g), _p(partials), S, _p(dbeta),
+                         _p(dgamma), K, M, _stream())
     return g
+
+
+def act_bwd_partial(dy, y_act, act, slope=0.0, need_g=True):
+    """g = dy * act'(y) (or None) and the slice partials [C, S] of its channel sums (no finalize launch)."""
+    dy, y_act = _chk(dy, "dy"), _chk(y_act, "y")
+    N, C, HW = _nchw(dy)
+    g = torch.empty_like(dy) if need_g else None
+    S = _ws_query("rg_bn_slices", N, C, HW)
+    part = torch.empty((C, S), dtype=torch.float32, device=dy.device)
+    lib.rg_act_bwd_partial(_p(dy), _p(y_act), _p(g), _p(part), N, C, HW, act, slope, _stream())
+    return g, part
 
 
 def fold_filters_multi(table, n_pairs, blocks):
