@@ -479,3 +479,94 @@ def test_bgemm_and_softmax(dev):
     xr = (ref * 1.0).requires_grad_(True)
     torch.softmax(xr * scale, dim=-1).backward(dp.double())
     _close(ds, xr.grad, name="softmax bwd")
+
+
+@pytest.mark.parametrize("case", [(3, 24, 12, 10, 40, 3, 1, 1), (2, 16, 17, 9, 24, 3, 2, 1), (2, 32, 16, 8, 64, 1, 2, 0),
+                                  (4, 64, 8, 4, 32, 4, 2, 1), (2, 3, 20, 12, 8, 7, 2, 3)])
+def test_dgrad_fused_epilogue(dev, case):
+    """dgrad epilogue: dx = mask(act(dgrad * scale[c] + shift[c] + residual)) on the stride-1 path, the strided parity-class
+    path, the 1x1/stride-2 path with empty classes and the small-C direct kernel."""
+    ops = _ops()
+    N, C, H, W, K, k, s, p = case
+    g = torch.Generator().manual_seed(21 + C)
+    w = torch.randn(K, C, k, k, generator=g) / math.sqrt(C * k * k)
+    P, Q = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, K, P, Q, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    mask = torch.randn(N, C, H, W, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    base = torch.nn.grad.conv2d_input((N, C, H, W), w.double(), dy.double(), stride=s, padding=p)
+    ref = base * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double()
+    got = ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p, scale=sc.to(dev), shift=sh.to(dev), residual=res.to(dev))
+    _close(got, ref, name="dgrad affine+res")
+    got = ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p, residual=res.to(dev), relu_mask=mask.to(dev))
+    _close(got, (base + res.double()) * (mask.double() > 0), name="dgrad res+mask")
+    got = ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p, shift=sh.to(dev), act=ops.ACT_LEAKY, slope=0.1,
+                           relu_mask=mask.to(dev))
+    _close(got, F.leaky_relu(base + sh.double().view(1, -1, 1, 1), 0.1) * (mask.double() > 0), name="dgrad act+mask")
+
+
+def test_bn_fold_ops(dev):
+    """conv + frozen BatchNorm fold: scale/shift/invstd, scaled filters (single pair and the multi-pair launch), and the
+    backward identities dgamma = invstd (sum W.G - mean sum g), dW = scale G against autograd through conv -> BN(eval) -> ReLU."""
+    ops = _ops()
+    from rg_hip import nn as rnn
+    g = torch.Generator().manual_seed(31)
+    N, C, H, W, K = 4, 24, 10, 6, 40
+    conv = torch.nn.Conv2d(C, K, 3, padding=1, bias=False).double()
+    bn = torch.nn.BatchNorm2d(K).double().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    y = F.relu(bn(conv(xr)))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    rconv, rbn = rnn.Conv2d(C, K, 3, padding=1, bias=False), rnn.BatchNorm2d(K)
+    rconv.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
+    rbn.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    rconv.to(dev), rbn.to(dev).eval()
+    grp = rnn.FoldGroup([(rconv, rbn)])
+    assert grp.usable()
+    grp.prepare()
+    f = rconv._rg_fold
+    inv = 1.0 / torch.sqrt(bn.running_var + bn.eps)
+    _close(f.scale, bn.weight * inv, name="scale")
+    _close(f.shift, bn.bias - bn.running_mean * bn.weight * inv, name="shift")
+    _close(f.w_scaled, conv.weight * (bn.weight * inv).view(-1, 1, 1, 1), name="scaled filters")
+    _close(f.w_scaled_krsc, (conv.weight * (bn.weight * inv).view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(K, 9, C),
+           name="scaled KRSC filters")
+    from rg_hip.tape import Tape
+    tape = Tape(param_grad=True)
+    yd = rnn.conv_bn_tf(tape, rconv, rbn, x.to(dev), act=ops.ACT_RELU)
+    _close(yd, y, name="fused forward")
+    dx = rnn.conv_bn_tb(tape, rconv, rbn, dy.to(dev))
+    _close(dx, xr.grad, name="dx")
+    _close(tape.grads[id(rconv.weight)], conv.weight.grad, tol=5e-5, name="dW")
+    _close(tape.grads[id(rbn.weight)], bn.weight.grad, tol=5e-5, name="dgamma")
+    _close(tape.grads[id(rbn.bias)], bn.bias.grad, tol=5e-5, name="dbeta")
+
+
+def test_error_paths(dev):
+    """the C ABI refuses instead of mis-computing: oversize tensors, bad geometry, k > cols, mismatched shapes"""
+    ops = _ops()
+    x = torch.zeros(1, 4, 8, 8, device=dev)
+    w = torch.zeros(4, 5, 3, 3, device=dev)
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x, w, 1, 1)                               # channel mismatch
+    with pytest.raises(RuntimeError) as e:
+        ops.conv2d_dgrad(torch.zeros(1, 4, 3, 3, device=dev), torch.zeros(4, 4, 3, 3, device=dev), (8, 8), 3, 1)
+    assert "stride" in str(e.value)
+    with pytest.raises(RuntimeError) as e:                      # geometry that no convolution produces
+        ops.conv2d_dgrad(torch.zeros(1, 4, 4, 4, device=dev), torch.zeros(4, 4, 3, 3, device=dev), (8, 8), 3, 1)
+    assert "larger than input" in str(e.value)
+    with pytest.raises(RuntimeError) as e:
+        ops.topk_rows(torch.zeros(2, 5, device=dev), 6)
+    assert "k must be <= cols" in str(e.value)
+    with pytest.raises(TypeError):
+        ops.conv2d_fwd(x.double(), torch.zeros(4, 4, 3, 3, device=dev), 1, 1)
+    i, v = ops.topk_rows(torch.tensor([[1.0, 3.0, 3.0, 2.0, -1.0]], device=dev), 5)          # k == cols, ties by lower index
+    assert i.cpu().tolist() == [[1, 2, 3, 0, 4]] and v.cpu().tolist() == [[3.0, 3.0, 2.0, 1.0, -1.0]]
