@@ -1,0 +1,217 @@
+// Pipeline study for the conv kernels' main loop on a plain GEMM C[M][N] = A[M][K] * B[K][N] (A k-contiguous = filters,
+// B n-contiguous = pixels of a 1x1 convolution), 128x128 tile, 256 threads, fp32 MFMA 32x32x2.
+//   v0: the scheme of conv_igemm.hip today — BK 16, global -> VGPR -> LDS, two LDS buffers, stores of tile t+1 interleaved
+//       into the last k-steps of tile t, one barrier per tile (prefetch distance 1)
+//   v1: three LDS buffers, prefetch distance 2 (loads of tile t+2 issued at the top of tile t, stored during tile t+1)
+//   v2: BK 32, two buffers (dynamic LDS, 67.6 KB)
+// usage: gemm_pipe_bench <variant> <tiles_per_cu 1|2|3> [K]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 256, BM = 128, BN = 128;
+
+template <int BK>
+struct Stage {
+    float4 a[BK / 8];      // A: 128 rows x BK k = 128*BK/4 float4 / 256 threads
+    float4 b[BK / 8];      // B: BK k x 128 n
+};
+
+template <int BK>
+__device__ __forceinline__ void gload(Stage<BK>& s, const float* __restrict__ A, const float* __restrict__ B, int K, int N,
+                                      int m0, int n0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        const int v = tid + NT * i;                  // A: v -> (row = v / (BK/4), kq = (v % (BK/4)) * 4)
+        const int row = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+        s.a[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + row) * K + k0 + kq);
+        const int kk = v / 32, nq = (v % 32) * 4;    // B: v -> (k = v / 32, n = (v % 32) * 4)
+        s.b[i] = *reinterpret_cast<const float4*>(B + (int64_t)(k0 + kk) * N + n0 + nq);
+    }
+}
+
+template <int BK, int LD>
+__device__ __forceinline__ void lstore(const Stage<BK>& s, float (*As)[LD], float (*Bs)[LD], int tid, int part, int parts) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        if ((i * parts) / (BK / 8) != part && part >= 0) continue;
+        const int v = tid + NT * i;
+        const int row = v / (BK / 4), kq = (v % (BK / 4)) * 4;
+        As[kq + 0][row] = s.a[i].x; As[kq + 1][row] = s.a[i].y; As[kq + 2][row] = s.a[i].z; As[kq + 3][row] = s.a[i].w;
+        const int kk = v / 32, nq = (v % 32) * 4;
+        *reinterpret_cast<float4*>(&Bs[kk][nq]) = s.b[i];
+    }
+}
+
+template <int BK, int LD, typename Hook>
+__device__ __forceinline__ void mma(const float (*As)[LD], const float (*Bs)[LD], floatx16 (&acc)[2][2], int wm, int wn, int lane,
+                                    Hook hook) {
+    const int l32 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+        const int k = 2 * ks + kh;
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[k][wm * 64 + i * 32 + l32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bs[k][wn * 64 + j * 32 + l32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        hook(ks);
+    }
+}
+
+__device__ __forceinline__ void store_c(float* C, int N, int m0, int n0, int wm, int wn, int lane, const floatx16 (&acc)[2][2]) {
+    const int l32 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                C[(int64_t)m * N + n0 + wn * 64 + j * 32 + l32] = acc[i][j][r];
+            }
+}
+
+// ---- v0: two buffers, distance 1 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_v0(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Stage<BK> st;
+    gload<BK>(st, A, B, K, N, m0, n0, 0, tid);
+    lstore<BK, LD>(st, As[0], Bs[0], tid, -1, 1);
+    __syncthreads();
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) gload<BK>(st, A, B, K, N, m0, n0, (kt + 1) * BK, tid);
+        mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+            if (has_next && ks >= BK / 4) lstore<BK, LD>(st, As[cur ^ 1], Bs[cur ^ 1], tid, ks - BK / 4, BK / 4);
+        });
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- v1: three buffers, distance 2 ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_v1(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132;
+    __shared__ __attribute__((aligned(16))) float As[3][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[3][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / BK;            // even, >= 4 in this benchmark
+    Stage<BK> s0, s1;                 // s0 holds tile kt+1 (to be stored during tile kt), s1 receives tile kt+2
+    gload<BK>(s0, A, B, K, N, m0, n0, 0, tid);
+    lstore<BK, LD>(s0, As[0], Bs[0], tid, -1, 1);
+    gload<BK>(s0, A, B, K, N, m0, n0, BK, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even half: store s0 (tile kt+1) while computing kt, load kt+2 into s1
+        if (kt + 2 < nk) gload<BK>(s1, A, B, K, N, m0, n0, (kt + 2) * BK, tid);
+        {
+            const int nb = (cur + 1) % 3;
+            mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+                if (kt + 1 < nk && ks >= BK / 4) lstore<BK, LD>(s0, As[nb], Bs[nb], tid, ks - BK / 4, BK / 4);
+            });
+            __syncthreads();
+            cur = nb;
+        }
+        if (kt + 1 >= nk) break;
+        // odd half: store s1 (tile kt+2) while computing kt+1, load kt+3 into s0
+        if (kt + 3 < nk) gload<BK>(s0, A, B, K, N, m0, n0, (kt + 3) * BK, tid);
+        {
+            const int nb = (cur + 1) % 3;
+            mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+                if (kt + 2 < nk && ks >= BK / 4) lstore<BK, LD>(s1, As[nb], Bs[nb], tid, ks - BK / 4, BK / 4);
+            });
+            __syncthreads();
+            cur = nb;
+        }
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- v2: BK 32, two buffers in dynamic LDS ------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_v2(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 32, LD = 132;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float(*As)[BK][LD] = reinterpret_cast<float(*)[BK][LD]>(smem);
+    float(*Bs)[BK][LD] = reinterpret_cast<float(*)[BK][LD]>(smem + 2 * BK * LD);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Stage<BK> st;
+    gload<BK>(st, A, B, K, N, m0, n0, 0, tid);
+    lstore<BK, LD>(st, As[0], Bs[0], tid, -1, 1);
+    __syncthreads();
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) gload<BK>(st, A, B, K, N, m0, n0, (kt + 1) * BK, tid);
+        mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+            if (has_next && ks >= BK / 4) lstore<BK, LD>(st, As[cur ^ 1], Bs[cur ^ 1], tid, ks - BK / 4, BK / 4);
+        });
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
+int main(int argc, char** argv) {
+    const int variant = argc > 1 ? atoi(argv[1]) : 0;
+    const int per_cu = argc > 2 ? atoi(argv[2]) : 1;
+    const int K = argc > 3 ? atoi(argv[3]) : 512;
+    const int M = 512, N = 128 * (256 * per_cu / (M / 128));       // tiles = (M/128) * (N/128) = 256 * per_cu
+    float *A, *B, *C;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)K * N * 4); hipMalloc(&C, (size_t)M * N * 4);
+    std::vector<float> ha((size_t)M * K), hb((size_t)K * N);
+    for (size_t i = 0; i < ha.size(); ++i) ha[i] = 0.01f * (float)((i * 7) % 13 - 6);
+    for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.02f * (float)((i * 5) % 11 - 5);
+    hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    const int blocks = (M / 128) * (N / 128);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 132 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        if (variant == 0) hipLaunchKernelGGL(gemm_v0, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else if (variant == 1) hipLaunchKernelGGL(gemm_v1, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else hipLaunchKernelGGL(gemm_v2, dim3(blocks), dim3(NT), 2 * 2 * 32 * 132 * 4, 0, A, B, C, M, N, K);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    // checksum against a host reference of a few entries
+    std::vector<float> hc((size_t)M * N);
+    hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0;
+    for (int t = 0; t < 64; ++t) {
+        const int m = (t * 37) % M, n = (t * 101) % N;
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)ha[(size_t)m * K + k] * hb[(size_t)k * N + n];
+        const double e = ref - hc[(size_t)m * N + n];
+        if ((e < 0 ? -e : e) > maxerr) maxerr = e < 0 ? -e : e;
+    }
+    printf("v%d  %d tile(s)/CU  M %d N %d K %d: %.1f us  %.1f TFLOP/s  (max err %.2e)\n", variant, per_cu, M, N, K, best * 1e3,
+           2.0 * M * N * K / best / 1e9, maxerr);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
