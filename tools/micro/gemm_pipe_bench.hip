@@ -174,6 +174,134 @@ __global__ __launch_bounds__(NT) void gemm_v2(const float* A, const float* B, fl
     store_c(C, N, m0, n0, wm, wn, lane, acc);
 }
 
+// ---- v3: three LDS buffers, ONE register stage: the tile loaded during tile t-1/t is stored into LDS in the FIRST k-steps
+// of tile t (buffer (t+2)%3, free since the barrier that ended tile t-1), the next loads are issued right behind the stores:
+// every global load has ~0.9 tile of matrix work between issue and first use --------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_v3(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132;
+    __shared__ __attribute__((aligned(16))) float As[3][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[3][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / BK;
+    Stage<BK> st;
+    gload<BK>(st, A, B, K, N, m0, n0, 0, tid);
+    lstore<BK, LD>(st, As[0], Bs[0], tid, -1, 1);
+    if (nk > 1) {
+        gload<BK>(st, A, B, K, N, m0, n0, BK, tid);
+        lstore<BK, LD>(st, As[1], Bs[1], tid, -1, 1);
+    }
+    if (nk > 2) gload<BK>(st, A, B, K, N, m0, n0, 2 * BK, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int wb = cur == 0 ? 2 : cur - 1;          // (cur + 2) % 3
+        mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+            if (ks == 0 && kt + 2 < nk) lstore<BK, LD>(st, As[wb], Bs[wb], tid, 0, 2);
+            if (ks == 1 && kt + 2 < nk) lstore<BK, LD>(st, As[wb], Bs[wb], tid, 1, 2);
+            if (ks == 1 && kt + 3 < nk) gload<BK>(st, A, B, K, N, m0, n0, (kt + 3) * BK, tid);
+        });
+        __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- v4: v0 with parts switched off at compile time (timing only, results wrong): -DNO_GLOAD / -DNO_LSTORE / -DNO_BARRIER -----
+__global__ __launch_bounds__(NT) void gemm_v4(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Stage<BK> st;
+    gload<BK>(st, A, B, K, N, m0, n0, 0, tid);
+    lstore<BK, LD>(st, As[0], Bs[0], tid, -1, 1);
+    lstore<BK, LD>(st, As[1], Bs[1], tid, -1, 1);
+    __syncthreads();
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+#ifndef NO_GLOAD
+        if (has_next) gload<BK>(st, A, B, K, N, m0, n0, (kt + 1) * BK, tid);
+#endif
+        mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+#ifndef NO_LSTORE
+            if (has_next && ks >= BK / 4) lstore<BK, LD>(st, As[cur ^ 1], Bs[cur ^ 1], tid, ks - BK / 4, BK / 4);
+#endif
+        });
+#ifndef NO_BARRIER
+        __syncthreads();
+#else
+        asm volatile("" ::: "memory");
+#endif
+        cur ^= 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
+// ---- v5: v0 with the A operand m-major in LDS ([128][20] floats): the k-contiguous global float4 goes to LDS with ONE
+// ds_write_b128 (instead of 4 transposed ds_write_b32) and one ds_read_b128 feeds 4 MFMA steps; MFMA step (h, s) of half kh
+// uses tile position p = 8h + 4kh + s for both operands (the order inside a k-tile is free) ------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(NT) void gemm_v5(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132, LA = 20;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    Stage<BK> st;
+    auto lst = [&](int buf, int part) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (part >= 0 && i != part) continue;
+            const int v = tid + NT * i;
+            const int row = v / 4, kq = (v % 4) * 4;
+            *reinterpret_cast<float4*>(&As[buf][row][kq]) = st.a[i];
+            const int kk = v / 32, nq = (v % 32) * 4;
+            *reinterpret_cast<float4*>(&Bs[buf][kk][nq]) = st.b[i];
+        }
+    };
+    gload<BK>(st, A, B, K, N, m0, n0, 0, tid);
+    lst(0, -1);
+    __syncthreads();
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) gload<BK>(st, A, B, K, N, m0, n0, (kt + 1) * BK, tid);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f4 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f4*>(&As[cur][wm * 64 + i * 32 + l32][8 * h + 4 * kh]);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int pos = 8 * h + 4 * kh + s_;
+                float b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = Bs[cur][pos][wn * 64 + j * 32 + l32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s_], b[j], acc[i][j], 0, 0, 0);
+                if (has_next && h == 1 && s_ >= 2) lst(cur ^ 1, s_ - 2);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
 int main(int argc, char** argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int per_cu = argc > 2 ? atoi(argv[2]) : 1;
@@ -182,8 +310,8 @@ int main(int argc, char** argv) {
     float *A, *B, *C;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)K * N * 4); hipMalloc(&C, (size_t)M * N * 4);
     std::vector<float> ha((size_t)M * K), hb((size_t)K * N);
-    for (size_t i = 0; i < ha.size(); ++i) ha[i] = 0.01f * (float)((i * 7) % 13 - 6);
-    for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.02f * (float)((i * 5) % 11 - 5);
+    for (size_t i = 0; i < ha.size(); ++i) ha[i] = 0.01f * (float)((int)((i * 7) % 13) - 6);
+    for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.02f * (float)((int)((i * 5) % 11) - 5);
     hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
     const int blocks = (M / 128) * (N / 128);
@@ -195,6 +323,9 @@ int main(int argc, char** argv) {
         hipEventRecord(e0);
         if (variant == 0) hipLaunchKernelGGL(gemm_v0, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 1) hipLaunchKernelGGL(gemm_v1, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else if (variant == 5) hipLaunchKernelGGL(gemm_v5, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else if (variant == 4) hipLaunchKernelGGL(gemm_v4, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else if (variant == 3) hipLaunchKernelGGL(gemm_v3, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else hipLaunchKernelGGL(gemm_v2, dim3(blocks), dim3(NT), 2 * 2 * 32 * 132 * 4, 0, A, B, C, M, N, K);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
