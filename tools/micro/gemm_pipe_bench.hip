@@ -40,7 +40,14 @@ __device__ __forceinline__ void lstore(const Stage<BK>& s, float (*As)[LD], floa
         const int row = v / (BK / 4), kq = (v % (BK / 4)) * 4;
         As[kq + 0][row] = s.a[i].x; As[kq + 1][row] = s.a[i].y; As[kq + 2][row] = s.a[i].z; As[kq + 3][row] = s.a[i].w;
         const int kk = v / 32, nq = (v % 32) * 4;
+#ifdef B_SCALAR_STORE
+        Bs[kk][nq + 0] = s.b[i].x; Bs[kk][nq + 1] = s.b[i].y; Bs[kk][nq + 2] = s.b[i].z; Bs[kk][nq + 3] = s.b[i].w;
+#elif defined(B_B64_STORE)
+        *reinterpret_cast<float2*>(&Bs[kk][nq]) = make_float2(s.b[i].x, s.b[i].y);
+        *reinterpret_cast<float2*>(&Bs[kk][nq + 2]) = make_float2(s.b[i].z, s.b[i].w);
+#else
         *reinterpret_cast<float4*>(&Bs[kk][nq]) = s.b[i];
+#endif
     }
 }
 
@@ -302,6 +309,52 @@ __global__ __launch_bounds__(NT) void gemm_v5(const float* A, const float* B, fl
     store_c(C, N, m0, n0, wm, wn, lane, acc);
 }
 
+// ---- v6: v0 with the A operand pre-transposed in GLOBAL memory (At[K][M], m contiguous — e.g. filters re-laid out once per
+// weight version): both operands are staged exactly like B (float4 along the tile row, one ds_write_b128 each, no transposed
+// scalar LDS writes) --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gemm_v6(const float* At, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 132;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[2], rb[2];
+    auto ld = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + NT * i, kk = v / 32, q = (v % 32) * 4;
+            ra[i] = *reinterpret_cast<const float4*>(At + (int64_t)(k0 + kk) * M + m0 + q);
+            rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(k0 + kk) * N + n0 + q);
+        }
+    };
+    auto stq = [&](int buf, int part) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (part >= 0 && i != (part >> 1)) continue;
+            const int v = tid + NT * i, kk = v / 32, q = (v % 32) * 4;
+            if (part < 0 || (part & 1) == 0) *reinterpret_cast<float4*>(&As[buf][kk][q]) = ra[i];
+            if (part < 0 || (part & 1) == 1) *reinterpret_cast<float4*>(&Bs[buf][kk][q]) = rb[i];
+        }
+    };
+    ld(0);
+    stq(0, -1);
+    __syncthreads();
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) ld((kt + 1) * BK);
+        mma<BK, LD>(As[cur], Bs[cur], acc, wm, wn, lane, [&](int ks) {
+            if (has_next && ks >= BK / 4) stq(cur ^ 1, ks - BK / 4);
+        });
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
 int main(int argc, char** argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int per_cu = argc > 2 ? atoi(argv[2]) : 1;
@@ -314,6 +367,13 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hb.size(); ++i) hb[i] = 0.02f * (float)((int)((i * 5) % 11) - 5);
     hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    float* At;
+    hipMalloc(&At, (size_t)M * K * 4);
+    {
+        std::vector<float> hat((size_t)M * K);
+        for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) hat[(size_t)k * M + m] = ha[(size_t)m * K + k];
+        hipMemcpy(At, hat.data(), hat.size() * 4, hipMemcpyHostToDevice);
+    }
     const int blocks = (M / 128) * (N / 128);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 132 * 4);
     hipEvent_t e0, e1;
@@ -323,6 +383,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e0);
         if (variant == 0) hipLaunchKernelGGL(gemm_v0, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 1) hipLaunchKernelGGL(gemm_v1, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
+        else if (variant == 6) hipLaunchKernelGGL(gemm_v6, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
         else if (variant == 5) hipLaunchKernelGGL(gemm_v5, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 4) hipLaunchKernelGGL(gemm_v4, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 3) hipLaunchKernelGGL(gemm_v3, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
