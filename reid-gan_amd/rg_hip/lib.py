@@ -88,6 +88,9 @@ class _Lib(object):
             raise ImportError(
                 "libreidgan_hip.so not found at %s — build it with `make -C %s` or __graft_entry__.build(); "
                 "there is no CPU / PyTorch fallback for the HIP path" % (LIB_PATH, CSRC_DIR))
+        # torch first: it brings its own HIP runtime (libamdhip64); loading this library before torch would bind the process
+        # to the system copy instead and torch's device context would not be the one the kernels launch into
+        import torch  # noqa: F401
         dll = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in self.protos.items():
             fn = getattr(dll, name)            # AttributeError if the header and library disagree
