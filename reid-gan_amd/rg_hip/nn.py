@@ -206,8 +206,12 @@ class _BatchNorm(RGModule):
         tape.push((x, y if act != ACT_NONE else None, mean, stat, is_var, batch_stats, act, slope, residual is not None))
         return y
 
-    def tb(self, tape, dy, need_dx=True):
+    def tb(self, tape, dy, need_dx=True, dy_masked=False):
+        """dy_masked: dy already went through this layer's activation backward (the consumer's dgrad epilogue applied the
+        ReLU mask, see Conv2d.tb(mask_input=True)), so the forward output is not read again."""
         x, y, mean, stat, is_var, train, act, slope, has_res = tape.pop()
+        if dy_masked:
+            act, y = ACT_NONE, None
         need_affine = tape.wants(self.weight) or tape.wants(self.bias)
         if not train and is_var:
             # running statistics: dx does not depend on the channel sums -> one fused pass
@@ -365,7 +369,7 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
     mask_input: apply the ReLU backward of the layer BELOW (whose output is this conv's input) to dx + residual."""
     rec = tape.pop()
     if rec is None:
-        r = bn.tb(tape, dy)                   # re-applying the mask to an already masked dy is a no-op
+        r = bn.tb(tape, dy, dy_masked=dy_masked)
         d, dres = r if isinstance(r, tuple) else (r, None)
         dx = conv.tb(tape, d, need_dx=need_dx, residual=residual, mask_input=mask_input)
         return (dx, dres) if isinstance(r, tuple) else dx
