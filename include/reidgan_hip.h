@@ -141,6 +141,13 @@ int rg_bicubic_normalize_bwd(const float* dy, float* dx, int N, int C, int H, in
  * the int64 device list (each distinct id once) */
 int rg_normalize_listed_rows(float* g, const void* ids, int n_ids, int rows, int D, float eps, rg_stream_t stream);
 
+/* mean(f(a + b*x)), f = ReLU when clamp != 0 else identity: hinge / wgangp / generator branches of the dual_gan GANLoss,
+ * CC/dual_gan/models/external_function.py:58-68; workspace as rg_loss_workspace() */
+int rg_affine_relu_mean_fwd(const float* x, float* loss, int64_t n, float a, float b, int clamp, void* workspace,
+                            size_t workspace_bytes, rg_stream_t stream);
+int rg_affine_relu_mean_bwd(const float* x, const float* grad_out, float* dx, int64_t n, float a, float b, int clamp,
+                            float grad_scale, rg_stream_t stream);
+
 /* ---- pseudo-labelling front half / evaluation distances ------------------------------ */
 /* faiss IndexFlatIP.search of CC/clustercontrast/utils/infomap_cluster.py:51-78 on a similarity block s[rows][cols]
  * (from the GEMM): the k best columns per row in (value descending, index ascending) order; idx int32 [rows][k] */

@@ -76,6 +76,27 @@ __global__ void mse_const_bwd_kernel(const float* __restrict__ x, const float* _
         dx[i] = g * (x[i] - target);
 }
 
+// mean(f(a + b * x)), f = ReLU (clamp != 0) or identity: the hinge / wgangp / generator branches of the dual_gan GANLoss
+// (CC/dual_gan/models/external_function.py:58-68): hinge D real ReLU(1 - x), D fake ReLU(1 + x), G / wgangp +-mean(x)
+__global__ __launch_bounds__(256) void affine_relu_mean_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                                       int64_t n, float a, float b, int clamp) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = a + b * x[i];
+        s += clamp ? fmaxf(v, 0.f) : v;
+    }
+    s = rg_block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void affine_relu_mean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout, float* __restrict__ dx,
+                                            int64_t n, float a, float b, int clamp, float scale) {
+    const float g = (gout ? gout[0] : 1.f) * scale * b;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = (!clamp || a + b * x[i] > 0.f) ? g : 0.f;
+}
+
 // L1 over rows selected by labels[row] == 1 (labels == NULL selects every row)
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          const int64_t* __restrict__ labels,
@@ -241,6 +262,27 @@ extern "C" int rg_mse_const_bwd(const float* x, const float* grad_out, float* dx
     hipLaunchKernelGGL(mse_const_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, grad_out, dx, n, target,
                        grad_scale / (float)n);
     return rg::check_launch("rg_mse_const_bwd");
+}
+
+extern "C" int rg_affine_relu_mean_fwd(const float* x, float* loss, int64_t n, float a, float b, int clamp, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+    RG_REQUIRE(x && loss && n > 0, "rg_affine_relu_mean_fwd: bad arguments");
+    RG_NEED_WS("rg_affine_relu_mean_fwd");
+    float* part = static_cast<float*>(workspace);
+    const unsigned g = partial_grid(n);
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 4.0 * n);
+    hipLaunchKernelGGL(affine_relu_mean_partial_kernel, dim3(g), dim3(256), 0, stream, x, part, n, a, b, clamp);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, stream, part, (int)g, loss, 1.f / (float)n);
+    return rg::check_launch("rg_affine_relu_mean_fwd");
+}
+
+extern "C" int rg_affine_relu_mean_bwd(const float* x, const float* grad_out, float* dx, int64_t n, float a, float b,
+                                       int clamp, float grad_scale, hipStream_t stream) {
+    RG_REQUIRE(x && dx && n > 0, "rg_affine_relu_mean_bwd: bad arguments");
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(affine_relu_mean_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, grad_out, dx, n, a, b, clamp,
+                       grad_scale / (float)n);
+    return rg::check_launch("rg_affine_relu_mean_bwd");
 }
 
 // out[0] = mean |a-b| over the selected rows, out[1] = 1/(selected elements) (kept for the backward)

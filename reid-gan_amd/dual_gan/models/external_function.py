@@ -1,9 +1,9 @@
 """Losses of the dual_gan models on the HIP kernels.
 
-Mirror of CC/dual_gan/models/external_function.py:14-69 (`GANLoss`).  `lsgan` — the default and only mode the
-training scripts run (`--gan_mode lsgan`, examples/options/train_options.py:28) — is built: one fused
-(x - label)^2 reduction kernel for the discriminator form, an element-wise kernel for the `reduction='none'` generator
-form.  `VGGLoss` / `VGG19` (:107-347) need torchvision's pretrained VGG-19 download; the scripts are run with
+Mirror of CC/dual_gan/models/external_function.py:14-69 (`GANLoss`).  All four modes are built: `lsgan` (the default of the
+training scripts, examples/options/train_options.py:28: one fused (x - label)^2 reduction for the discriminator form, an
+element-wise kernel for the `reduction='none'` generator form), `vanilla` (fused sigmoid-BCE), `hinge` and `wgangp`
+(`rg_affine_relu_mean_*`; the wgangp gradient PENALTY of `cal_gradient_penalty` needs a double backward and is not built).  `VGGLoss` / `VGG19` (:107-347) need torchvision's pretrained VGG-19 download; the scripts are run with
 `--no_vgg_loss` on the target machines (no network), so constructing one raises.
 """
 from __future__ import absolute_import
@@ -40,20 +40,26 @@ class GANLoss(nn.Module):
         self.register_buffer('fake_label', torch.tensor(target_fake_label))
         self._real, self._fake = float(target_real_label), float(target_fake_label)
         self.gan_mode = gan_mode
-        if gan_mode == 'lsgan':
-            self.loss = None
-        elif gan_mode in ('vanilla', 'hinge', 'wgangp'):
-            raise NotImplementedError("gan mode %s has no HIP kernels yet (the training scripts run lsgan)" % gan_mode)
-        else:
+        if gan_mode not in ('lsgan', 'vanilla', 'hinge', 'wgangp'):
             raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+        self.loss = None
 
     def label(self, target_is_real):
         return self._real if target_is_real else self._fake
 
     def __call__(self, prediction, target_is_real, is_disc=False):
-        if is_disc:
-            return RF.mse_const(prediction, self.label(target_is_real))
-        return _SquareDiffConst.apply(prediction, self.label(target_is_real))
+        if self.gan_mode == 'lsgan':
+            if is_disc:
+                return RF.mse_const(prediction, self.label(target_is_real))
+            return _SquareDiffConst.apply(prediction, self.label(target_is_real))
+        if self.gan_mode == 'vanilla':                       # BCEWithLogitsLoss (mean) in both forms (:55-57)
+            return RF.sigmoid_bce_const(prediction, self.label(target_is_real))
+        if is_disc:                                          # hinge / wgangp, discriminator form (:58-66)
+            sign = -1.0 if target_is_real else 1.0
+            if self.gan_mode == 'hinge':
+                return RF.affine_relu_mean(prediction, 1.0, sign, clamp=True)
+            return RF.affine_relu_mean(prediction, 0.0, sign, clamp=False)
+        return RF.affine_relu_mean(prediction, 0.0, -1.0, clamp=False)          # generator form: -mean(D(fake)) (:67-68)
 
 
 class VGGLoss(nn.Module):

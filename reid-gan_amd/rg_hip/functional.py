@@ -129,3 +129,21 @@ class _L2NormRows(torch.autograd.Function):
 def normalize_rows(x, eps=1e-12):
     """F.normalize(x, dim=1) for a [rows, D] tensor."""
     return _L2NormRows.apply(x, eps)
+
+
+class _AffineReluMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, b, clamp):
+        ctx.save_for_backward(x)
+        ctx.a, ctx.b, ctx.clamp = float(a), float(b), bool(clamp)
+        return ops.affine_relu_mean_fwd(x, ctx.a, ctx.b, ctx.clamp)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.affine_relu_mean_bwd(x, _scalar_grad(g), ctx.a, ctx.b, ctx.clamp), None, None, None
+
+
+def affine_relu_mean(x, a, b, clamp=True):
+    """mean(relu(a + b * x)) (clamp) or mean(a + b * x): hinge / wgangp GAN objectives in one fused reduction."""
+    return _AffineReluMean.apply(x, a, b, clamp)

@@ -724,6 +724,21 @@ def mse_const_bwd(x, grad_out, target, grad_scale=1.0):
     return dx
 
 
+def affine_relu_mean_fwd(x, a, b, clamp):
+    x = _chk(x, "x")
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = _loss_ws(x.device)
+    lib.rg_affine_relu_mean_fwd(_p(x), _p(loss), x.numel(), a, b, int(clamp), _p(ws), ws.numel(), _stream())
+    return loss
+
+
+def affine_relu_mean_bwd(x, grad_out, a, b, clamp, grad_scale=1.0):
+    x = _chk(x, "x")
+    dx = torch.empty_like(x)
+    lib.rg_affine_relu_mean_bwd(_p(x), _p(grad_out), _p(dx), x.numel(), a, b, int(clamp), grad_scale, _stream())
+    return dx
+
+
 def l1_fwd(a, b, row_labels=None):
     a, b = _chk(a, "a"), _chk(b, "b")
     row_labels = _chk(row_labels, "row_labels", torch.int64)

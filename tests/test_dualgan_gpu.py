@@ -325,3 +325,35 @@ def test_dptn_generator(dev):
         ti, si = rg(xs.to(dev), ps.to(dev), pt.to(dev), False)
     assert si is None
     _check(ti, on(xs, ps, pt, False)[0], 1e-3, "dptn inference out_t")
+
+
+def test_ganloss_modes(dev):
+    """external_function.GANLoss: lsgan / vanilla / hinge / wgangp, discriminator and generator forms, value + gradient."""
+    import torch.nn.functional as F
+    from dual_gan.models.external_function import GANLoss
+    g = torch.Generator().manual_seed(17)
+    pred = torch.randn(3, 1, 16, 8, generator=g) * 2
+
+    def ref(mode, x, real, disc):
+        if mode == 'lsgan':
+            l = (x - (1.0 if real else 0.0)) ** 2
+            return l.mean() if disc else l
+        if mode == 'vanilla':
+            return F.binary_cross_entropy_with_logits(x, torch.full_like(x, 1.0 if real else 0.0))
+        if disc:
+            xx = -x if real else x
+            return F.relu(1 + xx).mean() if mode == 'hinge' else xx.mean()
+        return -x.mean()
+    for mode in ('lsgan', 'vanilla', 'hinge', 'wgangp'):
+        crit = GANLoss(mode)
+        for real in (True, False):
+            for disc in (True, False):
+                xr = pred.double().requires_grad_(True)
+                xd = pred.to(dev).requires_grad_(True)
+                lr, ld = ref(mode, xr, real, disc), crit(xd, real, disc)
+                _check(ld, lr, 2e-5, "%s real=%s disc=%s" % (mode, real, disc))
+                lr.sum().backward()
+                (ld.sum() if ld.dim() else ld).backward()
+                _check(xd.grad, xr.grad, 2e-5, "%s grad" % mode)
+    with pytest.raises(NotImplementedError):
+        GANLoss('nonsense')
