@@ -250,7 +250,7 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         value = world * CROPS_PER_GPU * args.steps / elapsed
         out = {
-            "metric": "train-step images/sec, 256x128 ReID batch (FD-GAN step)",
+            "metric": "train-step images/sec, 256\u00d7128 ReID batch, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (random-init weights, seeded on-device 256x128 crops + 18-ch pose maps)",
