@@ -516,3 +516,40 @@ def test_joint_step_4b_fdgan_adaptor(dev):
         for k, v in rn.state_dict().items():
             if v.dtype == torch.float32 and "running" not in k:
                 assert (v.detach().double().cpu() - so[k].double()).abs().max().item() <= 3.0 * lr_adam, k
+
+
+def test_fdgan_step_through_rccl_reducers(dev, monkeypatch):
+    """The data-parallel path on one rank: torch.distributed over RCCL (backend "nccl"), the gradient arenas of all three
+    optimizers all-reduced in place (async, overlapped with the next backward; side / aux streams active).  With world
+    size 1 the collective is an identity, so two steps must reproduce the un-reduced run exactly."""
+    import torch.distributed as dist
+    from fdgan.model import FDGANModel
+    from oracle import ref_torch as O
+
+    def run(force):
+        monkeypatch.setenv("RG_FORCE_REDUCE", "1" if force else "0")
+        torch.manual_seed(5)
+        model = FDGANModel(_opt())
+        assert all(r.active() == force for r in model.reducers)
+        model.reset_model_status()
+        out = []
+        for it in range(2):
+            origin, target, pose, labels, noise = O.synth_fdgan_batch(2, seed=300 + it)
+            pid1 = torch.arange(2)
+            pid2 = torch.where(labels == 1, pid1, pid1 + 1000)
+            model.set_input((dict(pid=pid1, origin=origin[:2], target=target[:2], posemap=pose[:2], noise=noise[:2]),
+                             dict(pid=pid2, origin=origin[2:], target=target[2:], posemap=pose[2:])))
+            model.optimize_parameters()
+            out.append(model.get_current_errors())
+        return out
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+    try:
+        ref = run(False)
+        got = run(True)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(ref, got):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-6 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
