@@ -75,7 +75,14 @@ size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int 
 int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K,
                     int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
                     const float* shift, const float* residual, int act, float slope, const float* relu_mask,
-                    void* workspace, size_t workspace_bytes, rg_stream_t stream);
+                    float* rowsum, int rowsum_cols, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+/* rowsum (dgrad only, may be NULL): [C][rowsum_cols] — per input channel, the sums of the FINAL dx values over blocks of
+ * pixels (one column per class, pixel tile and wave column; fixed summation order).  Their sum over the columns is the
+ * per-channel sum of dx: exactly the `partials` rg_bn_fold_wgrad of the layer below needs (dbeta / dgamma), so that layer does
+ * not read dx again.  rowsum_cols must equal rg_conv2d_dgrad_rowsum_cols(...), which is 0 when the launch would use split-K
+ * or the small-C kernel (no fused row sums there). */
+int rg_conv2d_dgrad_rowsum_cols(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P,
+                                int Q);
 int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, rg_stream_t stream);
 /* development knob: pin the fwd/dgrad planner's tile (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x256) and split-K count;
  * (-1, -1) releases it (same effect as the RG_CONV_FORCE="tile,splits" environment variable) */

@@ -74,7 +74,9 @@ struct Epilogue {
     float slope;
     const float* mask;   // same shape as the output or nullptr: after the residual add, v = mask > 0 ? v : 0 (the ReLU
                          // backward of the layer that produced this conv's input, whose output IS that input)
-};
+    float* rowsum;       // nullptr or [M][rowsum_cols]: per GEMM row, the sum of the FINAL values this wave stored (one
+    int rowsum_cols;     // column per (class, n-tile, wave column) = the channel sums the BatchNorm fold of the layer
+};                       // below needs, rg_bn_fold_wgrad `partials`), written in fixed order: deterministic
 
 struct ConvP {
     const float* x;   // fwd: input, dgrad: dy, wgrad: input
@@ -95,7 +97,7 @@ struct ConvP {
 };
 
 struct DgradClass {
-    int r0, s0, nrh, nrw, Hc, Wc, Ngc, Kgc, ntiles;
+    int r0, s0, nrh, nrw, Hc, Wc, Ngc, Kgc, ntiles, poff;      // poff: first row-sum column block of the class
     FastDiv d_taps, d_nrw, d_hw, d_w;
 };
 
@@ -199,7 +201,7 @@ __device__ __forceinline__ void zero_acc(floatx16 (&acc)[T::TM][T::TN]) {
 // issued RB at a time before their first use (OOB lanes read 0 and their stores are dropped by the hardware).
 template <typename T, int ACT>
 __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], const unsigned (&ob)[T::TN],
-                                                    unsigned rstride, int mrow0) {
+                                                    unsigned rstride, int mrow0, int pc) {
     const rsrc_t ro = make_rsrc(p.y, p.y_bytes);
     const rsrc_t rr = make_rsrc(p.ep.res ? (const void*)p.ep.res : (const void*)p.y, p.ep.res ? p.y_bytes : 0u);
     const rsrc_t rm = make_rsrc(p.ep.mask ? (const void*)p.ep.mask : (const void*)p.y, p.ep.mask ? p.y_bytes : 0u);
@@ -211,7 +213,9 @@ __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int rb = 0; rb < 16; rb += RB) {
-            float sc[RB], sh[RB];
+            float sc[RB], sh[RB], rs[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) rs[q] = 0.f;
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const int r = rb + q;
@@ -232,6 +236,7 @@ __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx
 #pragma unroll
                     for (int q = 0; q < RB; ++q) rv[q] = bload(rr, off_of(q));
                 }
+                const bool colok = ob[j] != OOB;
                 if (has_mask) {                      // mask folded into the residual registers: sign carries it
                     float mv[RB];
 #pragma unroll
@@ -243,7 +248,9 @@ __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx
                         if (ACT == RG_ACT_RELU) v = fmaxf(v, 0.f);
                         if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
                         if (ACT == RG_ACT_TANH) v = tanhf(v);
-                        bstore(ro, off_of(q), mv[q] > 0.f ? v : 0.f);
+                        v = mv[q] > 0.f ? v : 0.f;
+                        bstore(ro, off_of(q), v);
+                        if (p.ep.rowsum) rs[q] += colok ? v : 0.f;
                     }
                 } else {
 #pragma unroll
@@ -254,21 +261,34 @@ __device__ __forceinline__ void store_tile_epilogue(const ConvP& p, const floatx
                         if (ACT == RG_ACT_LEAKY) v = v > 0.f ? v : v * p.ep.slope;
                         if (ACT == RG_ACT_TANH) v = tanhf(v);
                         bstore(ro, off_of(q), v);
+                        if (p.ep.rowsum) rs[q] += colok ? v : 0.f;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads from being hoisted (VGPR pressure)
+            }
+            if (p.ep.rowsum) {                           // uniform: 32-lane butterfly per row, lane 0 of each half writes
+                const int lane = threadIdx.x & 63;
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    float t = rs[q];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                    const int r = rb + q;
+                    const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if ((lane & 31) == 0 && m < p.M) p.ep.rowsum[(int64_t)m * p.ep.rowsum_cols + pc] = t;
+                }
             }
         }
 }
 
 template <typename T>
 __device__ __forceinline__ void store_tile_epilogue_any(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN],
-                                                        const unsigned (&ob)[T::TN], unsigned rstride, int mrow0) {
+                                                        const unsigned (&ob)[T::TN], unsigned rstride, int mrow0, int pc) {
     switch (p.ep.act) {      // uniform
-        case RG_ACT_RELU: store_tile_epilogue<T, RG_ACT_RELU>(p, acc, ob, rstride, mrow0); break;
-        case RG_ACT_LEAKY: store_tile_epilogue<T, RG_ACT_LEAKY>(p, acc, ob, rstride, mrow0); break;
-        case RG_ACT_TANH: store_tile_epilogue<T, RG_ACT_TANH>(p, acc, ob, rstride, mrow0); break;
-        default: store_tile_epilogue<T, RG_ACT_NONE>(p, acc, ob, rstride, mrow0); break;
+        case RG_ACT_RELU: store_tile_epilogue<T, RG_ACT_RELU>(p, acc, ob, rstride, mrow0, pc); break;
+        case RG_ACT_LEAKY: store_tile_epilogue<T, RG_ACT_LEAKY>(p, acc, ob, rstride, mrow0, pc); break;
+        case RG_ACT_TANH: store_tile_epilogue<T, RG_ACT_TANH>(p, acc, ob, rstride, mrow0, pc); break;
+        default: store_tile_epilogue<T, RG_ACT_NONE>(p, acc, ob, rstride, mrow0, pc); break;
     }
 }
 
@@ -278,10 +298,10 @@ __device__ __forceinline__ void store_tile_epilogue_any(const ConvP& p, const fl
 template <typename T>
 __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
                                                 int wm, int wn, int lane, int Ng, int PIX, const FastDiv& d_pix,
-                                                int split) {
+                                                int split, int pcol = 0) {
     const int l32 = lane & 31, kh = lane >> 5;
     const int mrow0 = m0 + wm * T::WTM + 4 * kh;
-    const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && !p.ep.mask && p.ep.act == RG_ACT_NONE;
+    const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && !p.ep.mask && !p.ep.rowsum && p.ep.act == RG_ACT_NONE;
     if (p.partial || plain) {
         const rsrc_t ro = p.partial ? make_rsrc(p.partial, p.partial_bytes) : make_rsrc(p.y, p.y_bytes);
         const unsigned rstride = (p.partial ? (unsigned)Ng : (unsigned)PIX) * 4u;    // bytes between GEMM rows
@@ -318,7 +338,7 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
             ob[j] = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
         }
     }
-    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)PIX * 4u, mrow0);
+    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)PIX * 4u, mrow0, pcol);
 }
 
 // A operand loader shared by fwd (weights [M][Kg], k contiguous): float4 along k (AVEC) or scalar.
@@ -692,7 +712,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
     }
 
     if (p.SH == 1 && p.SW == 1) {       // one class: output pixels are contiguous, shared epilogue (+ split-K)
-        store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split);
+        store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * WN + wn);
         return;
     }
     // strided classes: pixel (hc, wc) of the class lands on (ah + SH*hc, aw + SW*wc); same fused epilogue
@@ -713,7 +733,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
             ob[j] = (unsigned)((((int64_t)im * p.C + mrow0) * HW + h * p.W + w) * 4);
         }
     }
-    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)HW * 4u, mrow0);
+    store_tile_epilogue_any<T>(p, acc, ob, (unsigned)HW * 4u, mrow0, (cl.poff + nt) * WN + wn);
 }
 
 // Data gradient for layers with <= 4 input channels (the RGB stem, FD/reid/models/resnet.py via torchvision conv1;
@@ -1205,7 +1225,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     ConvP p;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = x; p.w = w; p.y = y;
-    p.ep = Epilogue{scale, shift, residual, act, slope, nullptr};
+    p.ep = Epilogue{scale, shift, residual, act, slope, nullptr, nullptr, 0};
     p.M = K; p.Ng = N * P * Q; p.Kg = C * KH * KW;
     p.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
     p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
@@ -1255,18 +1275,22 @@ extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, i
 
 // w_krsc: the weights re-laid out as [K][KH*KW][C] by rg_weights_to_krsc (may be NULL; for 1x1 filters the
 // original tensor already has that layout and is used directly).
-extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H,
-                               int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
-                               const float* scale, const float* shift, const float* residual, int act, float slope,
-                               const float* relu_mask, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+namespace {
+// `dry` != nullptr: plan only (as if the queried workspace were supplied) and report the number of row-sum column blocks the
+// launch would write (0: split-K or the small-C kernel, which have no fused row sums); nothing is launched.
+int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K, int KH, int KW,
+               int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift, const float* residual,
+               int act, float slope, const float* relu_mask, float* rowsum, int rowsum_cols, void* workspace,
+               size_t workspace_bytes, hipStream_t stream, int* dry) {
     if (int e = validate("rg_conv2d_dgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
-    RG_REQUIRE(dy && w && dx, "rg_conv2d_dgrad: null tensor");
+    RG_REQUIRE(dry || (dy && w && dx), "rg_conv2d_dgrad: null tensor");
     RG_REQUIRE(SH <= 2 && SW <= 2, "rg_conv2d_dgrad: stride > 2 not supported (got %d,%d)", SH, SW);
+    if (dry) *dry = 0;
     DgradP dp;
     ConvP& p = dp.c;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = dy; p.w = w; p.y = dx;
-    p.ep = Epilogue{scale, shift, residual, act, slope, relu_mask};
+    p.ep = Epilogue{scale, shift, residual, act, slope, relu_mask, rowsum, rowsum_cols};
     p.M = C;
     p.x_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
     p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
@@ -1294,6 +1318,8 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
         }
     const bool one_class = SH == 1 && SW == 1;
     if (C <= 4 && (size_t)K * KH * KW * 4 * sizeof(float) <= 64 * 1024) {      // RGB-sized outputs: direct kernel
+        if (dry) return RG_OK;
+        RG_REQUIRE(!rowsum, "rg_conv2d_dgrad: row sums are not available on the small-C path (query rg_conv2d_dgrad_rowsum_cols)");
         int nmax = 0;
         for (int i = 0; i < SH * SW; ++i)
             if (dp.cls[i].Ngc > nmax) nmax = dp.cls[i].Ngc;
@@ -1328,16 +1354,27 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
     GemmPlan pl = one_class ? plan_gemm(p.M, ng_max, kg_max, true) : plan_gemm(p.M, ng_eff > 0 ? ng_eff : ng_max, kg_eff, false);
     if (!one_class) pl.ktiles_per_split = 1 << 30;       // planned on the MEAN depth: every class runs its full reduction
     const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
-    if (need > workspace_bytes || (need && !workspace)) {
+    if (!dry && (need > workspace_bytes || (need && !workspace))) {
         pl.splits = 1;
         pl.ktiles_per_split = 1 << 30;
     }
     p.m_tiles = pl.m_tiles;
-    int nt_max = 0;
+    int nt_max = 0, nt_sum = 0;
     for (int i = 0; i < SH * SW; ++i) {
         dp.cls[i].ntiles = rg::cdiv(dp.cls[i].Ngc, kTileBN[pl.tile]);
+        dp.cls[i].poff = nt_sum;
+        nt_sum += dp.cls[i].ntiles;
         if (dp.cls[i].ntiles > nt_max) nt_max = dp.cls[i].ntiles;
     }
+    const int wn_waves = pl.tile == 3 ? 4 : 2;            // wave columns of the tile shapes in RG_TILE_SWITCH
+    const int cols = pl.splits > 1 ? 0 : nt_sum * wn_waves;
+    if (dry) {
+        *dry = cols;
+        return RG_OK;
+    }
+    RG_REQUIRE(!rowsum || (cols > 0 && rowsum_cols == cols),
+               "rg_conv2d_dgrad: rowsum_cols %d does not match this launch (%d; query rg_conv2d_dgrad_rowsum_cols)", rowsum_cols,
+               cols);
     p.n_tiles = nt_max;
     p.Ng = (int)ng_max;
     p.Kg = K * KH * KW;
@@ -1353,6 +1390,27 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
                            p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
     }
     return rg::check_launch("rg_conv2d_dgrad");
+}
+}  // namespace
+
+extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H,
+                               int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
+                               const float* scale, const float* shift, const float* residual, int act, float slope,
+                               const float* relu_mask, float* rowsum, int rowsum_cols, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+    return dgrad_impl(dy, w, w_krsc, dx, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, scale, shift, residual, act, slope,
+                      relu_mask, rowsum, rowsum_cols, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Number of row-sum column blocks rg_conv2d_dgrad writes for this geometry when given the workspace of
+// rg_conv2d_dgrad_workspace (0: the launch uses split-K or the small-C kernel, which do not produce row sums).
+extern "C" int rg_conv2d_dgrad_rowsum_cols(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW,
+                                           int P, int Q) {
+    int cols = 0;
+    if (dgrad_impl(nullptr, nullptr, nullptr, nullptr, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, nullptr, nullptr, nullptr,
+                   0, 0.f, nullptr, nullptr, 0, nullptr, 0, nullptr, &cols) != RG_OK)
+        return 0;
+    return cols;
 }
 
 extern "C" int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, hipStream_t stream) {
@@ -1402,7 +1460,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     ConvP p;
     fill_common(p, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q);
     p.x = x; p.w = dy;
-    p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f, nullptr};
+    p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0};
     p.M = K; p.Ng = C * KH * KW; p.Kg = N * P * Q;
     const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
     p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;

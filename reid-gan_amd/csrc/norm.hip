@@ -463,8 +463,10 @@ __global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(const float* __restr
     const float* wr = w + (int64_t)k * M;
     float* gr = g + (int64_t)k * M;
     float sg = 0.f;
-    if (part) {                       // channel sum of g from the slice partials of rg_act_bwd_partial (fixed order)
-        for (int s = 0; s < S; ++s) sg += part[(int64_t)k * S + s];
+    if (part) {                       // channel sum of g from slice / tile partials (fixed tree: deterministic)
+        float t = 0.f;
+        for (int s = threadIdx.x; s < S; s += 256) t += part[(int64_t)k * S + s];
+        sg = rg_block_sum(t, red);
         if (dbeta && threadIdx.x == 0) dbeta[k] = sg;
     } else if (sum_g) {
         sg = sum_g[k];

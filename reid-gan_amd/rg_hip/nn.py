@@ -67,7 +67,7 @@ class Conv2d(RGModule, _KrscCache):
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
 
-    def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False, dx_channels=None):
+    def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False, dx_channels=None, want_rowsum=False):
         """mask_input: the conv's input x is the ReLU output of the layer below — its backward (zero where x <= 0) is
         applied to dx (+ residual) in the dgrad epilogue.  dx_channels=(c0, c1): only that channel range of the input
         receives a gradient (the rest of a concatenated input is constant) -> dx has c1 - c0 channels."""
@@ -85,7 +85,7 @@ class Conv2d(RGModule, _KrscCache):
             c0, c1 = dx_channels
             return ops.conv2d_dgrad(dy, self.weight.detach()[:, c0:c1].contiguous(), x.shape[2:], self.stride, self.padding)
         return ops.conv2d_dgrad(dy, self.weight, x.shape[2:], self.stride, self.padding, residual=residual,
-                                w_krsc=self._krsc(), relu_mask=x if mask_input else None)
+                                w_krsc=self._krsc(), relu_mask=x if mask_input else None, want_rowsum=want_rowsum)
 
 
 class ConvTranspose2d(RGModule, _KrscCache):
@@ -363,7 +363,7 @@ def conv_bn_tf(tape, conv, bn, x, residual=None, act=ACT_NONE):
     return y
 
 
-def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False, mask_input=False):
+def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False, mask_input=False, want_rowsum=None):
     """-> dx, or (dx, d_residual) when the forward had a residual input; `residual` here is added to dx.
     dy_masked: dy already carries this layer's ReLU backward (the consumer's dgrad applied it, see mask_input);
     mask_input: apply the ReLU backward of the layer BELOW (whose output is this conv's input) to dx + residual."""
@@ -373,6 +373,8 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
         d, dres = r if isinstance(r, tuple) else (r, None)
         dx = conv.tb(tape, d, need_dx=need_dx, residual=residual, mask_input=mask_input)
         return (dx, dres) if isinstance(r, tuple) else dx
+    if want_rowsum is None:
+        want_rowsum = mask_input and tape.param_grad      # the layer below is a fold that will want the channel sums
     x, y, f, act, has_res = rec
     want_w, want_g, want_b = tape.wants(conv.weight), tape.wants(bn.weight), tape.wants(bn.bias)
     need_sum = want_g or want_b
@@ -387,7 +389,9 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
     else:
         g = dy
         if fused_sums:
-            part = ops.act_bwd_partial(dy, None, ACT_NONE, need_g=False)[1]
+            part = getattr(dy, "_rg_rowsum", None) if dy_masked else None      # written by the dgrad epilogue that made dy
+            if part is None:
+                part = ops.act_bwd_partial(dy, None, ACT_NONE, need_g=False)[1]
         elif need_sum:
             sg = ops.act_bwd_sum(dy, None, ACT_NONE, need_g=False, need_sum=True, out_sum=ob)[1]
     dbeta = None
@@ -411,7 +415,7 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
     dx = None
     if need_dx:
         dx = ops.conv2d_dgrad(g, f.w_scaled, x.shape[2:], conv.stride, conv.padding, residual=residual,
-                              w_krsc=f.w_scaled_krsc, relu_mask=x if mask_input else None)
+                              w_krsc=f.w_scaled_krsc, relu_mask=x if mask_input else None, want_rowsum=want_rowsum)
     return (dx, g) if has_res else dx
 
 

@@ -120,7 +120,7 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
 
 
 def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, residual=None, act=ACT_NONE, slope=0.0,
-                 w_krsc=None, relu_mask=None):
+                 w_krsc=None, relu_mask=None, want_rowsum=False):
     """dx[N][C][H][W] from dy[N][K][P][Q] and w[K][C][KH][KW]; x_hw = (H, W) of the conv input.
     Also the forward of ConvTranspose2d (weight [in=K][out=C][KH][KW], output size x_hw)."""
     dy, w = _chk(dy, "dy"), _chk(w, "w")
@@ -142,9 +142,17 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
     relu_mask = _chk(relu_mask, "relu_mask")
     if relu_mask is not None and relu_mask.shape != dx.shape:
         raise ValueError("conv2d_dgrad: relu_mask shape mismatch")
+    rowsum, cols = None, 0
+    if want_rowsum:
+        # per-channel sums of the final dx in column blocks, written by the epilogue (0 columns: split-K / small-C launch)
+        cols = _ws_query("rg_conv2d_dgrad_rowsum_cols", N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q)
+        if cols > 0:
+            rowsum = torch.empty((C, cols), dtype=torch.float32, device=dy.device)
     lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(w_krsc), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale),
-                        _p(shift), _p(residual), act, slope, _p(relu_mask), _p(ws), ws.numel() if ws is not None else 0,
-                        _stream())
+                        _p(shift), _p(residual), act, slope, _p(relu_mask), _p(rowsum), cols, _p(ws),
+                        ws.numel() if ws is not None else 0, _stream())
+    if rowsum is not None:
+        dx._rg_rowsum = rowsum          # rides with the gradient to the BatchNorm fold of the layer below (nn.conv_bn_tb)
     return dx
 
 

@@ -570,3 +570,28 @@ def test_error_paths(dev):
         ops.conv2d_fwd(x.double(), torch.zeros(4, 4, 3, 3, device=dev), 1, 1)
     i, v = ops.topk_rows(torch.tensor([[1.0, 3.0, 3.0, 2.0, -1.0]], device=dev), 5)          # k == cols, ties by lower index
     assert i.cpu().tolist() == [[1, 2, 3, 0, 4]] and v.cpu().tolist() == [[3.0, 3.0, 2.0, 1.0, -1.0]]
+
+
+@pytest.mark.parametrize("case", [(48, 64, 32, 16, 64, 3, 1, 1), (32, 32, 33, 17, 48, 3, 2, 1), (32, 64, 32, 16, 128, 1, 2, 0),
+                                  (32, 40, 24, 20, 24, 1, 1, 0), (2, 64, 8, 4, 64, 3, 1, 1)])
+def test_dgrad_rowsum(dev, case):
+    """the row sums a dgrad launch writes next to dx add up to dx.sum over (n, h, w) per channel — including residual + mask"""
+    ops = _ops()
+    N, C, H, W, K, k, s, p = case
+    g = torch.Generator().manual_seed(41 + C)
+    w = torch.randn(K, C, k, k, generator=g) / math.sqrt(C * k * k)
+    P, Q = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, K, P, Q, generator=g)
+    res = torch.randn(N, C, H, W, generator=g)
+    mask = torch.randn(N, C, H, W, generator=g)
+    wk = ops.weights_to_krsc(w.to(dev)) if (k > 1 and C % 4 == 0) else None
+    dx = ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p, residual=res.to(dev), relu_mask=mask.to(dev), w_krsc=wk,
+                          want_rowsum=True)
+    part = getattr(dx, "_rg_rowsum", None)
+    from rg_hip.lib import lib
+    cols = lib.rg_conv2d_dgrad_rowsum_cols(N, C, H, W, K, k, k, s, s, p, p, P, Q)
+    if cols == 0:                       # split-K launch: no fused row sums, the consumer falls back to its own pass
+        assert part is None and N == 2
+        return
+    assert part is not None and tuple(part.shape) == (C, cols)
+    _close(part.sum(1), dx.double().sum((0, 2, 3)), tol=2e-5, name="row sums")
