@@ -155,8 +155,16 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
 #else
         // stores of the next tile in the last TWO k-steps: the global loads issued at the top of the tile get 6/8 of its
         // matrix work as cover before their first use (measured: -0.7 ms per FD-GAN step, +2-4 % on the N = 32 layers)
+#if defined(RG_STORE_LAST)
+        if (ks == BK / 2 - 1) { hook(0); hook(1); hook(2); hook(3); }
+#elif defined(RG_STORE_3)
+        if (ks == BK / 2 - 3) { hook(0); }
+        if (ks == BK / 2 - 2) { hook(1); }
+        if (ks == BK / 2 - 1) { hook(2); hook(3); }
+#else
         if (ks == BK / 2 - 2) { hook(0); hook(1); }
         if (ks == BK / 2 - 1) { hook(2); hook(3); }
+#endif
 #endif
     }
 }
