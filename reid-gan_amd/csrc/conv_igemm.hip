@@ -145,11 +145,17 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
         for (int i = 0; i < T::TM; ++i) a[i] = As[k][wm * T::WTM + i * 32 + l32];
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) b[j] = Bs[k][wn * T::WTN + j * 32 + l32];
+#ifdef RG_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int j = 0; j < T::TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#ifdef RG_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef RG_EARLY_STORE
         if (ks >= BK / 4) hook(ks - BK / 4);                  // stores of the next tile spread over the last four k-steps
 #else
