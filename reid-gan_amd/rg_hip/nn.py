@@ -62,10 +62,21 @@ class Conv2d(RGModule, _KrscCache):
 
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         """y = act(conv(x) + bias + residual): bias, residual add and activation run in the MFMA epilogue."""
-        y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, residual=residual, act=act,
-                           slope=slope, w_krsc=self._krsc())
+        if self._full_extent(x):
+            # the filter covers the whole (unpadded) map — the generator's 512 -> 128 (8,4) bottleneck,
+            # FD/fdgan/networks.py:96-100: a plain GEMM x[N][C*H*W] . w[K][C*KH*KW]^T, run with 1x1 geometry
+            K = self.weight.shape[0]
+            y = ops.conv2d_fwd(x.view(x.shape[0], -1, 1, 1), self.weight.view(K, -1, 1, 1), 1, 0, shift=self.bias,
+                               residual=residual, act=act, slope=slope)
+        else:
+            y = ops.conv2d_fwd(x, self.weight, self.stride, self.padding, shift=self.bias, residual=residual, act=act,
+                               slope=slope, w_krsc=self._krsc())
         tape.push((x, y if act != ACT_NONE else None, act, slope))
         return y
+
+    def _full_extent(self, x):
+        return (tuple(x.shape[2:]) == self.kernel_size and self.padding == (0, 0) and self.kernel_size != (1, 1)
+                and x.is_contiguous())
 
     def tb(self, tape, dy, need_dx=True, residual=None, mask_input=False, dx_channels=None, want_rowsum=False):
         """mask_input: the conv's input x is the ReLU output of the layer below — its backward (zero where x <= 0) is
@@ -81,6 +92,9 @@ class Conv2d(RGModule, _KrscCache):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
+        if self._full_extent(x) and dx_channels is None and residual is None and not mask_input and not want_rowsum:
+            K = self.weight.shape[0]
+            return ops.conv2d_dgrad(dy, self.weight.view(K, -1, 1, 1), (1, 1), 1, 0).view(x.shape)
         if dx_channels is not None:
             c0, c1 = dx_channels
             return ops.conv2d_dgrad(dy, self.weight.detach()[:, c0:c1].contiguous(), x.shape[2:], self.stride, self.padding)
@@ -138,6 +152,11 @@ class ConvTranspose2d(RGModule, _KrscCache):
             tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
         if not need_dx:
             return None
+        if (x.shape[2] == 1 and x.shape[3] == 1 and self.padding == (0, 0) and self.output_padding == (0, 0)
+                and tuple(dy.shape[2:]) == self.kernel_size and dy.is_contiguous()):
+            # 1x1 input (see tf): dx[N][K] = dy[N][C*KH*KW] . w[K][C*KH*KW]^T, no (r,s)-major filter copy needed
+            K = self.weight.shape[0]
+            return ops.conv2d_fwd(dy.view(dy.shape[0], -1, 1, 1), self.weight.view(K, -1, 1, 1), 1, 0, residual=residual)
         return ops.conv2d_fwd(dy, self.weight, self.stride, self.padding, residual=residual, w_krsc=self._krsc())
 
 
