@@ -818,6 +818,118 @@ __global__ __launch_bounds__(256) void conv_dgrad_smallc_kernel(const DgradP dp)
     }
 }
 
+// Register-tiled form of the small-C data gradient for <= 4 taps per axis and class (7x7 / 2, 4x4 / 2, 3x3 / 1):
+// lanes run along a class row (coalesced loads of dy), each thread owns PX consecutive class ROWS of one column, so
+// one broadcast filter read serves PX pixels and the PX + NRH - 1 gradient rows are loaded once per channel and
+// slide across the vertical taps in registers.  The plain kernel above issues one global load and one LDS read per
+// 3 FMAs and is bound by the load path.  Branch-free inner loops: rows / columns outside dy are buffer loads with an
+// out-of-range offset (-> 0).
+template <int PX, int NRH, int NRW>
+__device__ __forceinline__ void smallc_px_accumulate(const ConvP& p, const DgradClass& cl, const float* wl, int img,
+                                                     int hb0, int wb, float (&acc)[PX][3]) {
+    constexpr int WR = PX + NRH - 1;
+    const int RS = p.KH * p.KW, PQ = p.P * p.Q;
+    const rsrc_t rdy = make_rsrc(p.x, p.x_bytes);
+    // pixel i (class row hc0 + i), tap (j, jj) reads dy[pp = hb0 + i - j][q = wb - jj]: window row r = i + NRH-1 - j
+    const unsigned imgoff = (unsigned)img * (unsigned)p.K * (unsigned)PQ * 4u;
+    unsigned off[WR][NRW];
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+        const int pp = hb0 - (NRH - 1) + r;
+        const unsigned rowoff = (unsigned)pp < (unsigned)p.P ? imgoff + (unsigned)(pp * p.Q) * 4u : OOB;
+#pragma unroll
+        for (int jj = 0; jj < NRW; ++jj) {
+            const int q = wb - jj;
+            const unsigned qo = (unsigned)q < (unsigned)p.Q ? (unsigned)q * 4u : OOB;
+            off[r][jj] = ((rowoff | qo) & OOB) ? OOB : rowoff + qo;
+        }
+    }
+    const float* wbase = wl + (cl.r0 * p.KW + cl.s0) * 4;
+#pragma unroll 2
+    for (int ko = 0; ko < p.K; ++ko) {
+        float v[WR][NRW];
+        const unsigned koff = (unsigned)ko * (unsigned)PQ * 4u;          // an out-of-range offset stays out of range
+#pragma unroll
+        for (int r = 0; r < WR; ++r)
+#pragma unroll
+            for (int jj = 0; jj < NRW; ++jj) v[r][jj] = bload(rdy, off[r][jj] + koff);
+#pragma unroll
+        for (int j = 0; j < NRH; ++j)
+#pragma unroll
+            for (int jj = 0; jj < NRW; ++jj) {
+                const float4 wv = *reinterpret_cast<const float4*>(wbase + (ko * RS + p.SH * j * p.KW + p.SW * jj) * 4);
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    acc[i][0] += v[i + NRH - 1 - j][jj] * wv.x;
+                    acc[i][1] += v[i + NRH - 1 - j][jj] * wv.y;
+                    acc[i][2] += v[i + NRH - 1 - j][jj] * wv.z;
+                }
+            }
+    }
+}
+
+template <int PX>
+__global__ __launch_bounds__(256) void conv_dgrad_smallc_px_kernel(const DgradP dp) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [K][RS][4]
+    const ConvP& p = dp.c;
+    // block id = 8*ncls*a + 8*ci + x -> pixel region 8a + x of class ci: the classes of one region read the same rows
+    // of dy, so they run back to back on the same XCD (ids are dealt round-robin over the 8 XCDs) and share its L2
+    const int ncls = p.SH * p.SW;
+    const int ci = (blockIdx.x >> 3) % ncls;
+    const int region = (int)(blockIdx.x / (8 * ncls)) * 8 + (blockIdx.x & 7);
+    const DgradClass& cl = dp.cls[ci];
+    const int ah = ci / p.SW, aw = ci % p.SW;
+    const int RS = p.KH * p.KW, HW = p.H * p.W;
+    const int Hg = (cl.Hc + PX - 1) / PX;
+    if (cl.Hc <= 0 || cl.Wc <= 0 || region * (int)blockDim.x >= p.N * Hg * cl.Wc) return;   // uniform
+    for (int i = threadIdx.x; i < p.K * RS * 4; i += blockDim.x) {
+        const int c = i & 3, t = i >> 2;               // t = ko*RS + rs
+        wl[i] = c < p.C ? p.w[(int64_t)(t / RS) * p.C * RS + c * RS + (t % RS)] : 0.f;
+    }
+    __syncthreads();
+    const int n = region * blockDim.x + threadIdx.x;
+    if (n >= p.N * Hg * cl.Wc) return;
+    const int img = n / (Hg * cl.Wc);
+    const int rem = n - img * Hg * cl.Wc;
+    const int hg = rem / cl.Wc;
+    const int wc = rem - hg * cl.Wc;
+    const int hc0 = hg * PX;
+    const int hb0 = (ah + p.SH * hc0 + p.PH - cl.r0) / p.SH;
+    const int wb = (aw + p.SW * wc + p.PW - cl.s0) / p.SW;
+    float acc[PX][3];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
+#define RG_SMALLC_CASE(NRH_, NRW_) \
+    case NRH_ * 8 + NRW_: smallc_px_accumulate<PX, NRH_, NRW_>(p, cl, wl, img, hb0, wb, acc); break
+    switch (cl.nrh * 8 + cl.nrw) {                      // uniform per block
+        RG_SMALLC_CASE(1, 1); RG_SMALLC_CASE(1, 2); RG_SMALLC_CASE(1, 3); RG_SMALLC_CASE(1, 4);
+        RG_SMALLC_CASE(2, 1); RG_SMALLC_CASE(2, 2); RG_SMALLC_CASE(2, 3); RG_SMALLC_CASE(2, 4);
+        RG_SMALLC_CASE(3, 1); RG_SMALLC_CASE(3, 2); RG_SMALLC_CASE(3, 3); RG_SMALLC_CASE(3, 4);
+        RG_SMALLC_CASE(4, 1); RG_SMALLC_CASE(4, 2); RG_SMALLC_CASE(4, 3); RG_SMALLC_CASE(4, 4);
+        default: break;                                 // no tap reaches this class: zeros (+ epilogue)
+    }
+#undef RG_SMALLC_CASE
+    const int w = aw + p.SW * wc;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        if (hc0 + i >= cl.Hc) break;
+        const int h = ah + p.SH * (hc0 + i);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c < p.C) {
+                float v = acc[i][c];
+                if (p.ep.scale) v *= p.ep.scale[c];
+                if (p.ep.shift) v += p.ep.shift[c];
+                const int64_t o = ((int64_t)img * p.C + c) * HW + h * p.W + w;
+                if (p.ep.res) v += p.ep.res[o];
+                v = rg_apply_act(v, p.ep.act, p.ep.slope);
+                if (p.ep.mask && !(p.ep.mask[o] > 0.f)) v = 0.f;
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
 // out[(img*M + m)*PIX + pix] = act((sum_s partial[s][m][n]) * scale[m] + shift[m] + res), n = img*PIX + pix
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial,
                                                                  float* __restrict__ out, int M, int Ng, int PIX,
@@ -1342,8 +1454,20 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
         p.Ng = nmax;
         p.Kg = K * KH * KW;
         rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops);
-        hipLaunchKernelGGL((conv_dgrad_smallc_kernel<4>), dim3(rg::cdiv(nmax, 256), 1, SH * SW), dim3(256),
-                           (size_t)K * KH * KW * 4 * sizeof(float), stream, dp);
+        bool few_taps = C <= 3;
+        int gmax = 0;
+        for (int i = 0; i < SH * SW; ++i) {
+            few_taps = few_taps && dp.cls[i].nrw <= 4 && dp.cls[i].nrh <= 4;
+            const int g = N * rg::cdiv(dp.cls[i].Hc, 4) * dp.cls[i].Wc;
+            if (g > gmax) gmax = g;
+        }
+        static const int px_env = getenv("RG_SMALLC_PX") ? atoi(getenv("RG_SMALLC_PX")) : 1;
+        if (few_taps && px_env && gmax > 0)
+            hipLaunchKernelGGL((conv_dgrad_smallc_px_kernel<4>), dim3(((rg::cdiv(gmax, 256) + 7) / 8) * 8 * SH * SW), dim3(256),
+                               (size_t)K * KH * KW * 4 * sizeof(float), stream, dp);
+        else
+            hipLaunchKernelGGL((conv_dgrad_smallc_kernel<4>), dim3(rg::cdiv(nmax, 256), 1, SH * SW), dim3(256),
+                               (size_t)K * KH * KW * 4 * sizeof(float), stream, dp);
         return rg::check_launch("rg_conv2d_dgrad(small-C)");
     }
     // weight operand layout / loader

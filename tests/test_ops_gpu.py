@@ -52,6 +52,11 @@ CONV_CASES = [
     (32, 512, 31, 15, 1, 4, 4, 1, 1),    # D_pd head at full batch: M = 1, deep split-K
     (2, 256, 16, 8, 1024, 1, 1, 2, 0),   # downsample 1x1 stride 2 (empty parity classes in dgrad)
     (2, 20, 12, 6, 36, 3, 3, 1, 1),      # C % 4 == 0 but tiny: KRSC path with ragged tiles
+    (2, 3, 19, 13, 8, 7, 7, 2, 3),       # RGB data gradient, odd sizes: ragged pixel groups of the small-C kernel
+    (1, 3, 9, 7, 5, 3, 3, 1, 1),         # small-C, stride 1 (one class, 3 taps per axis)
+    (2, 2, 10, 6, 6, 4, 4, 2, 1),        # small-C with 2 channels
+    (1, 3, 12, 9, 4, 5, 5, 1, 2),        # small-C, 5 taps per axis: the one-pixel-per-thread kernel
+    (2, 4, 10, 6, 6, 3, 3, 2, 1),        # C = 4: one-pixel-per-thread kernel
 ]
 
 
