@@ -930,6 +930,103 @@ __global__ __launch_bounds__(256) void conv_dgrad_smallc_px_kernel(const DgradP 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-output-channel convolutions (the PatchGAN heads: FD/fdgan/networks.py:225-226 Conv(512 -> 1, 4, 1, 1),
+// CC/dual_gan/models/networks.py:946 ResDiscriminator's final conv): a 32-row MFMA tile would be 97 % padding and the
+// layer is a 30 MB read with 0.2 GFLOP, so these are direct VALU kernels bound by the read of x.  Lanes run along the
+// output pixels (coalesced rows of x, every element re-used KH*KW times out of L1); the input channels (forward) or
+// the pixels (weight gradient) are sliced across blockIdx.y and the slices are summed by the ordinary split-K
+// finishing kernels (same partial layout [slice][M = 1][n]), in fixed order: deterministic.
+// ---------------------------------------------------------------------------------------------
+struct ThinP {
+    const float* x;
+    const float* a;      // fwd: w [1][C][KH][KW]; wgrad: dy [N][1][P][Q]
+    float* partial;
+    int N, C, H, W, P, Q, SH, SW, PH, PW, per_slice;
+    unsigned x_bytes;
+    FastDiv d_pq, d_q;
+};
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_fwd_k1_kernel(const ThinP t) {
+    const int Ng = t.N * t.P * t.Q;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= Ng) return;
+    const int img = fdiv(pix, t.d_pq);
+    const int pq = pix - img * t.P * t.Q;
+    const int pp = fdiv(pq, t.d_q), qq = pq - pp * t.Q;
+    const int h0 = pp * t.SH - t.PH, w0 = qq * t.SW - t.PW;
+    const rsrc_t rx = make_rsrc(t.x, t.x_bytes);
+    unsigned off[KH][KW];
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+            const int h = h0 + r, w = w0 + s;
+            off[r][s] = ((unsigned)h < (unsigned)t.H && (unsigned)w < (unsigned)t.W)
+                            ? (unsigned)((img * t.C * t.H + h) * t.W + w) * 4u : OOB;
+        }
+    const int c0 = blockIdx.y * t.per_slice;
+    const int c1 = min(c0 + t.per_slice, t.C);
+    const unsigned cstride = (unsigned)(t.H * t.W) * 4u;
+    float acc = 0.f;
+#pragma unroll 2
+    for (int c = c0; c < c1; ++c) {
+        const float* wc = t.a + c * (KH * KW);          // uniform: scalar loads
+        const unsigned co = (unsigned)c * cstride;      // an out-of-range offset stays out of range
+#pragma unroll
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) acc += bload(rx, off[r][s] + co) * wc[r * KW + s];
+    }
+    t.partial[(int64_t)blockIdx.y * Ng + pix] = acc;
+}
+
+// grid (C, slices): block (c, s) reduces pixels [s*per_slice, (s+1)*per_slice) for the KH*KW taps of channel c
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const ThinP t) {
+    constexpr int RS = KH * KW;
+    __shared__ float red[4][RS];
+    const int Ng = t.N * t.P * t.Q;
+    const int c = blockIdx.x;
+    const int beg = blockIdx.y * t.per_slice;
+    const int end = min(beg + t.per_slice, Ng);
+    const rsrc_t rx = make_rsrc(t.x, t.x_bytes);
+    float acc[KH][KW];
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) acc[r][s] = 0.f;
+    for (int pix = beg + threadIdx.x; pix < end; pix += 256) {
+        const int img = fdiv(pix, t.d_pq);
+        const int pq = pix - img * t.P * t.Q;
+        const int pp = fdiv(pq, t.d_q), qq = pq - pp * t.Q;
+        const int h0 = pp * t.SH - t.PH, w0 = qq * t.SW - t.PW;
+        const float g = t.a[pix];
+        const int base = (img * t.C + c) * t.H;
+#pragma unroll
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                const int h = h0 + r, w = w0 + s;
+                const bool ok = (unsigned)h < (unsigned)t.H && (unsigned)w < (unsigned)t.W;
+                acc[r][s] += g * bload(rx, ok ? (unsigned)((base + h) * t.W + w) * 4u : OOB);
+            }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+            const float v = rg_wave_sum(acc[r][s]);
+            if (lane == 0) red[wid][r * KW + s] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < RS)
+        t.partial[((int64_t)blockIdx.y * t.C + c) * RS + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // out[(img*M + m)*PIX + pix] = act((sum_s partial[s][m][n]) * scale[m] + shift[m] + res), n = img*PIX + pix
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial,
                                                                  float* __restrict__ out, int M, int Ng, int PIX,
@@ -1337,7 +1434,42 @@ static unsigned finish_grid(int64_t n) {
         default: LAUNCH(32, 256, 1, 4); break; \
     }
 
+namespace {
+// one-output-channel layers (conv_fwd_k1_kernel / conv_wgrad_k1_kernel): filter sizes with an instantiation
+static bool thin_filter(int K, int KH, int KW) {
+    static const int env = getenv("RG_THIN_CONV") ? atoi(getenv("RG_THIN_CONV")) : 1;
+    return env && K == 1 && ((KH == 4 && KW == 4) || (KH == 3 && KW == 3));
+}
+// forward: channels per slice so that ~2048 workgroups exist (>= 4 channels each)
+static int thin_fwd_per_slice(int C, int64_t Ng) {
+    int64_t slices = rg::cdiv64(2048, rg::cdiv64(Ng, 256));
+    if (slices > C / 4) slices = C / 4;
+    if (slices < 1) slices = 1;
+    return (int)rg::cdiv64(C, slices);
+}
+// weight gradient: pixels per slice so that ~2048 workgroups exist (>= 512 pixels each)
+static int thin_wgrad_per_slice(int C, int64_t Ng) {
+    int64_t slices = rg::cdiv64(2048, C);
+    if (slices > Ng / 512) slices = Ng / 512;
+    if (slices < 1) slices = 1;
+    return (int)rg::cdiv64(Ng, slices);
+}
+static void thin_fill(ThinP& t, const float* x, const float* a, float* partial, int N, int C, int H, int W, int SH, int SW,
+                      int PH, int PW, int P, int Q, int per_slice) {
+    t.x = x; t.a = a; t.partial = partial;
+    t.N = N; t.C = C; t.H = H; t.W = W; t.P = P; t.Q = Q; t.SH = SH; t.SW = SW; t.PH = PH; t.PW = PW;
+    t.per_slice = per_slice;
+    t.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
+    t.d_pq = make_fastdiv(P * Q);
+    t.d_q = make_fastdiv(Q);
+}
+}  // namespace
+
 extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
+    if (thin_filter(K, KH, KW)) {
+        const int64_t Ng = (int64_t)N * P * Q;
+        return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)Ng * sizeof(float);
+    }
     const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
     return pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
 }
@@ -1358,6 +1490,23 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     p.x_bytes = (unsigned)((int64_t)N * C * H * W * 4);
     p.w_bytes = (unsigned)((int64_t)K * C * KH * KW * 4);
     p.y_bytes = (unsigned)((int64_t)N * K * P * Q * 4);
+    if (thin_filter(K, KH, KW)) {
+        const int per = thin_fwd_per_slice(C, p.Ng);
+        const int slices = rg::cdiv(C, per);
+        const size_t need = (size_t)slices * (size_t)p.Ng * sizeof(float);
+        if (workspace && need <= workspace_bytes) {
+            ThinP t;
+            thin_fill(t, x, w, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
+            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * (double)p.Ng * p.Kg);
+            const dim3 grid(rg::cdiv(p.Ng, 256), slices);
+            if (KH == 4) hipLaunchKernelGGL((conv_fwd_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
+            else hipLaunchKernelGGL((conv_fwd_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
+            if (int e = rg::check_launch("rg_conv2d_fwd(thin)")) return e;
+            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.Ng)), dim3(256), 0, stream,
+                               t.partial, y, 1, p.Ng, P * Q, p.d_pq, slices, p.ep);
+            return rg::check_launch("rg_conv2d_fwd(thin finish)");
+        }
+    }
     const bool is1x1 = KH == 1 && KW == 1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
     const bool avec = (p.Kg % 4 == 0) && aligned;
@@ -1587,6 +1736,10 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
 }  // namespace
 
 extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
+    if (thin_filter(K, KH, KW)) {
+        const int64_t Ng = (int64_t)N * P * Q;
+        return (size_t)rg::cdiv64(Ng, thin_wgrad_per_slice(C, Ng)) * (size_t)C * KH * KW * sizeof(float);
+    }
     const WgradPlan pl = plan_wgrad(K, C * KH * KW, (int64_t)N * P * Q);
     return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
 }
@@ -1602,6 +1755,24 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     p.x = x; p.w = dy;
     p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0};
     p.M = K; p.Ng = C * KH * KW; p.Kg = N * P * Q;
+    if (thin_filter(K, KH, KW)) {
+        const int per = thin_wgrad_per_slice(C, p.Kg);
+        const int slices = rg::cdiv(p.Kg, per);
+        const size_t need_thin = (size_t)slices * (size_t)p.Ng * sizeof(float);
+        if (workspace && need_thin <= workspace_bytes) {
+            ThinP t;
+            thin_fill(t, x, dy, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
+            rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * (double)p.Ng * p.Kg);
+            const dim3 grid(C, slices);
+            if (KH == 4) hipLaunchKernelGGL((conv_wgrad_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
+            else hipLaunchKernelGGL((conv_wgrad_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
+            if (int e = rg::check_launch("rg_conv2d_wgrad(thin)")) return e;
+            const int64_t n = (int64_t)p.Ng;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
+                               static_cast<const float*>(workspace), dw, n, slices, 0, C, KH * KW);
+            return rg::check_launch("rg_conv2d_wgrad(thin reduce)");
+        }
+    }
     const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
     p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;

@@ -57,6 +57,8 @@ CONV_CASES = [
     (2, 2, 10, 6, 6, 4, 4, 2, 1),        # small-C with 2 channels
     (1, 3, 12, 9, 4, 5, 5, 1, 2),        # small-C, 5 taps per axis: the one-pixel-per-thread kernel
     (2, 4, 10, 6, 6, 3, 3, 2, 1),        # C = 4: one-pixel-per-thread kernel
+    (3, 40, 9, 7, 1, 3, 3, 2, 1),        # one output channel, 3x3 / 2 (direct kernels, channel / pixel slices)
+    (5, 130, 20, 12, 1, 4, 4, 1, 1),     # one output channel, ragged channel slices
 ]
 
 
