@@ -37,6 +37,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 16;
+#ifndef RG_WAVES
+#define RG_WAVES 4      // waves per SIMD the fwd / dgrad kernels are compiled for (register budget 512 / RG_WAVES; 4 = 128
+                        // registers: 2-5 spilled dwords outside the k-loop, +0.8 % on the step over 3)
+#endif
 constexpr int LPAD = 4;
 constexpr int NT = 256;
 
@@ -381,7 +385,7 @@ struct ALoadK {
 //           BMODE 2: 1x1 / stride 1 / pad 0 with H*W % 4 == 0: pixel operand as float4
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_fwd_kernel(const ConvP p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) void conv_fwd_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
 // MODE 2: MODE 1 layout + 1x1 / stride 1 / pad 0 with P*Q % 4 == 0: dy loads as float4 too (any K)
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv_dgrad_kernel(const DgradP dp) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) void conv_dgrad_kernel(const DgradP dp) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
