@@ -134,8 +134,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called after k-steps 4..7: the kernels use it to write the
-// NEXT tile's staged registers into the other LDS buffer, a quarter at a time, so those ds_writes (and the vmcnt
+// One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called behind the last k-step(s): the kernels use it to write
+// the NEXT tile's staged registers into the other LDS buffer, a quarter at a time, so those ds_writes (and the vmcnt
 // wait in front of them) issue in the shadow of the 64-cycle MFMAs instead of after them.
 template <typename T, typename Hook>
 __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float (*Bs)[T::LDB],
@@ -163,17 +163,18 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
 #ifdef RG_EARLY_STORE
         if (ks >= BK / 4) hook(ks - BK / 4);                  // stores of the next tile spread over the last four k-steps
 #else
-        // stores of the next tile in the last TWO k-steps: the global loads issued at the top of the tile get 6/8 of its
-        // matrix work as cover before their first use (measured: -0.7 ms per FD-GAN step, +2-4 % on the N = 32 layers)
-#if defined(RG_STORE_LAST)
-        if (ks == BK / 2 - 1) { hook(0); hook(1); hook(2); hook(3); }
+        // stores of the next tile behind the LAST k-step: the global loads issued at the top of the tile get 7/8 of its
+        // matrix work as cover before their first use.  Measured at 3 waves/SIMD: last two k-steps -0.7 ms per FD-GAN
+        // step over the last four; at 4 waves/SIMD: last k-step only +1.5 % on the conv family over the last two
+#if defined(RG_STORE_2)
+        if (ks == BK / 2 - 2) { hook(0); hook(1); }
+        if (ks == BK / 2 - 1) { hook(2); hook(3); }
 #elif defined(RG_STORE_3)
         if (ks == BK / 2 - 3) { hook(0); }
         if (ks == BK / 2 - 2) { hook(1); }
         if (ks == BK / 2 - 1) { hook(2); hook(3); }
 #else
-        if (ks == BK / 2 - 2) { hook(0); hook(1); }
-        if (ks == BK / 2 - 1) { hook(2); hook(3); }
+        if (ks == BK / 2 - 1) { hook(0); hook(1); hook(2); hook(3); }
 #endif
 #endif
     }
