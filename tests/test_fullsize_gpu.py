@@ -1,0 +1,193 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (the oracle finishes only reduced sizes in seconds, so the
+parity tests proper run small; these cover what only shows at full size: the tile / split-K plans of 32-crop layers,
+31-bit offsets, the XCD remap, side-stream overlap):
+
+* adjoint identities of the three convolution kernels on every layer geometry of the FD-GAN step at 32 crops of
+  256x128:  <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>  (three different kernels / tilings per layer);
+* batch-split invariance of the frozen-BN ResNet-50 encoder at 32 crops;
+* the whole FD-GAN step at batch 16 pairs (config 2): bit-identical losses and generated images between two runs and
+  between the overlapped (side streams) and the single-stream launch order;
+* ClusterMemory at B = 64, K = 2048, D = 2048 (config 3): touched centroids stay unit-norm, untouched rows bit-equal,
+  the input gradient uses the pre-update bank;
+* kNN at Market-1501 size (12 936 x 2048, k = 15): sorted, self first, idempotent.
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _resnet50_geoms(H, W, l4_stride=2):
+    out = [(3, H, W, 64, 7, 2, 3)]
+    h, w = H // 4, W // 4
+    cin = 64
+    for width, n, s in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, l4_stride)):
+        for bi in range(n):
+            st = s if bi == 0 else 1
+            out.append((cin, h, w, width, 1, 1, 0))
+            out.append((width, h, w, width, 3, st, 1))
+            if bi == 0:
+                out.append((cin, h, w, width * 4, 1, st, 0))
+            h, w = h // st, w // st
+            out.append((width, h, w, width * 4, 1, 1, 0))
+            cin = width * 4
+    return out
+
+
+# generator / discriminator layers (FD/fdgan/networks.py:86-138, 204-226) as (C, H, W, K, k, stride, pad)
+_GAN_GEOMS = [(18, 256, 128, 64, 4, 2, 1), (64, 128, 64, 128, 4, 2, 1), (128, 64, 32, 256, 4, 2, 1),
+              (256, 32, 16, 512, 4, 2, 1), (512, 16, 8, 512, 4, 2, 1), (21, 256, 128, 64, 4, 2, 1),
+              (256, 32, 16, 512, 4, 1, 1), (512, 31, 15, 1, 4, 1, 1), (3, 256, 128, 64, 4, 2, 1)]
+
+
+def _uniq(geoms):
+    seen, out = set(), []
+    for g in geoms:
+        if g not in seen:
+            seen.add(g)
+            out.append(g)
+    return out
+
+
+def test_conv_adjoint_identities_at_full_batch(dev):
+    from rg_hip import ops
+    N = 32
+    gen = torch.Generator(device=dev).manual_seed(5)
+    worst = 0.0
+    for C, H, W, K, k, s, p in _uniq(_resnet50_geoms(256, 128) + _resnet50_geoms(256, 128, 1) + _GAN_GEOMS):
+        x = torch.randn(N, C, H, W, generator=gen, device=dev)
+        w = torch.randn(K, C, k, k, generator=gen, device=dev) / math.sqrt(C * k * k)
+        y = ops.conv2d_fwd(x, w, s, p)
+        dy = torch.randn(y.shape, generator=gen, device=dev)
+        dx = ops.conv2d_dgrad(dy, w, (H, W), s, p)
+        dw = ops.conv2d_wgrad(x, dy, (K, C, k, k), s, p)
+        a = (y.double() * dy.double()).sum().item()
+        b = (x.double() * dx.double()).sum().item()
+        c = (w.double() * dw.double()).sum().item()
+        # Cauchy-Schwarz scale of the inner product; fp32 accumulation over C*k*k (fwd), K*k*k (dgrad), N*P*Q (wgrad) terms
+        scale = y.double().norm().item() * dy.double().norm().item()
+        err = max(abs(a - b), abs(a - c)) / scale
+        worst = max(worst, err)
+        assert err <= 2e-6, "adjoint identity broken for N=%d C=%d %dx%d -> K=%d k%d s%d p%d: %.6g %.6g %.6g (rel %.2e)" % (
+            N, C, H, W, K, k, s, p, a, b, c, err)
+        assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    assert worst > 0.0          # the three kernels are different programs: exact equality would mean they were not run
+
+
+def test_encoder_batch_split_invariance_at_32_crops(dev):
+    import reid.models as RM
+    torch.manual_seed(3)
+    net = RM.create("resnet50", cut_at_pooling=True, pretrained=False).to(dev).eval()
+    x = torch.randn(32, 3, 256, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    with torch.no_grad():
+        full = net(x)
+        halves = torch.cat([net(x[:16]), net(x[16:])])
+        singles = torch.cat([net(x[i:i + 1]) for i in (0, 17, 31)])
+    assert full.shape == (32, 2048)
+    scale = full.abs().max().item()
+    # different batch sizes take different tile / split-K plans: equal up to fp32 summation order
+    assert (full - halves).abs().max().item() <= 2e-5 * scale
+    assert (full[[0, 17, 31]] - singles).abs().max().item() <= 2e-5 * scale
+
+
+def _fdgan_two_steps(dev, overlap):
+    import bench as HB
+    from fdgan.model import FDGANModel
+    from rg_hip import ops
+    ops.side_enable(overlap)
+    old_aux = os.environ.get("RG_AUX_STREAM")
+    os.environ["RG_AUX_STREAM"] = "1" if overlap else "0"
+    try:
+        torch.manual_seed(1234)
+        torch.cuda.manual_seed_all(1234)
+        opt = HB.fdgan_opt()                       # config 2: batch 16 pairs = 32 crops, stage 2, dropout 0.2
+        model = FDGANModel(opt)
+        model.reset_model_status()
+        data = HB.synth_inputs(opt.batch_size, dev, seed=100)
+        torch.manual_seed(99)
+        out = []
+        for _ in range(2):
+            model.set_input(data)
+            model.optimize_parameters()
+            errs = model.get_current_errors()
+            out.append((dict(errs), model.fake.detach().clone()))
+        torch.cuda.synchronize()
+        return out
+    finally:
+        ops.side_enable(True)
+        if old_aux is None:
+            os.environ.pop("RG_AUX_STREAM", None)
+        else:
+            os.environ["RG_AUX_STREAM"] = old_aux
+
+
+def test_fdgan_step_config2_deterministic_and_overlap_neutral(dev):
+    a = _fdgan_two_steps(dev, overlap=True)
+    b = _fdgan_two_steps(dev, overlap=True)
+    c = _fdgan_two_steps(dev, overlap=False)
+    for step in range(2):
+        ea, fa = a[step]
+        assert fa.shape == (32, 3, 256, 128) and torch.isfinite(fa).all()
+        assert all(math.isfinite(float(v)) for v in ea.values()), ea
+        for other, what in ((b, "second run"), (c, "single-stream launch order")):
+            eo, fo = other[step]
+            assert {k: float(v) for k, v in ea.items()} == {k: float(v) for k, v in eo.items()}, (what, step, ea, eo)
+            assert torch.equal(fa, fo), "generated images differ (%s, step %d)" % (what, step)
+    # tanh output range, and the second step really moved the generator
+    assert a[0][1].abs().max().item() <= 1.0
+    assert not torch.equal(a[0][1], a[1][1])
+
+
+def test_cluster_memory_properties_at_config3_size(dev):
+    from clustercontrast.models.cm import ClusterMemory
+    g = torch.Generator(device=dev).manual_seed(8)
+    K, D, B = 2048, 2048, 64
+    bank = F.normalize(torch.randn(K, D, generator=g, device=dev), dim=1)
+    mem = ClusterMemory(D, K, temp=0.05, momentum=0.1).to(dev)
+    mem.features = bank.clone()
+    x = (torch.randn(B, D, generator=g, device=dev) * 3).requires_grad_(True)
+    labels = torch.randint(0, K, (16,), generator=g, device=dev).repeat_interleave(4)     # 16 identities x 4 instances
+    loss = mem(x, labels)
+    assert loss.shape == (B,)
+    xn = F.normalize(x.detach(), dim=1)
+    logits = (xn.double() @ bank.double().t()) / 0.05
+    ref = F.cross_entropy(logits, labels, reduction="none")
+    assert (loss.double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    loss.mean().backward()
+    # d loss / d normalized input uses the bank BEFORE the momentum update (CC/clustercontrast/models/cm.py:22-33)
+    p = torch.softmax(logits, 1)
+    p[torch.arange(B, device=dev), labels] -= 1
+    g_xn = (p / 0.05 / B) @ bank.double()
+    nrm = x.detach().double().norm(dim=1, keepdim=True)
+    g_x = (g_xn - xn.double() * (g_xn * xn.double()).sum(1, keepdim=True)) / nrm
+    assert (x.grad.double() - g_x).abs().max().item() <= 1e-5 * g_x.abs().max().item() + 1e-9
+    touched = torch.zeros(K, dtype=torch.bool, device=dev)
+    touched[labels] = True
+    assert torch.equal(mem.features[~touched], bank[~touched])                 # untouched centroids bit-equal
+    assert not torch.equal(mem.features[touched], bank[touched])
+    assert (mem.features[touched].double().norm(dim=1) - 1).abs().max().item() <= 1e-6
+
+
+def test_knn_properties_at_market1501_size(dev):
+    from clustercontrast.utils.infomap_cluster import knn_faiss
+    g = torch.Generator(device=dev).manual_seed(21)
+    n, D, k = 12936, 2048, 15
+    feats = F.normalize(torch.randn(n, D, generator=g, device=dev), dim=1)
+    idx = knn_faiss(feats, k)
+    nbrs, sims = idx.nbrs.cpu().to(torch.long), idx.sims.cpu()          # inner products, best first
+    assert nbrs.shape == (n, k) and sims.shape == (n, k)
+    assert (nbrs[:, 0] == torch.arange(n)).all()                               # self first (unit rows: similarity 1 is the max)
+    assert (nbrs >= 0).all() and (nbrs < n).all()
+    assert all(len(set(r.tolist())) == k for r in nbrs[::997])                  # no duplicate neighbours
+    assert (sims[:, 1:] <= sims[:, :-1]).all() and (sims[:, 0] - 1).abs().max().item() <= 1e-5     # sorted, self = 1
+    d0 = idx.knns[5000][1]                    # the reference's (nbrs, 1 - similarity) pairs (infomap_cluster.py:61-78)
+    assert abs(float(d0[0])) <= 1e-5 and (d0[1:] >= d0[:-1]).all()
+    rows = torch.tensor([0, 5000, n - 1])
+    ip = (feats[rows].double() @ feats.double().t()).cpu()
+    rv, ri = torch.topk(ip, k, dim=1)
+    assert torch.equal(ri, nbrs[rows])
+    assert torch.equal(nbrs, knn_faiss(feats, k).nbrs.cpu().to(torch.long))     # deterministic, ties included
