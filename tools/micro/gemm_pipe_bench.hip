@@ -355,6 +355,54 @@ __global__ __launch_bounds__(NT) void gemm_v6(const float* At, const float* B, f
     store_c(C, N, m0, n0, wm, wn, lane, acc);
 }
 
+// ---- v7: both operands by LDS-DMA (global_load_lds_dwordx4 from At[K][M] / B[K][N]): no VGPR staging and no ds_write at all.
+// NB LDS buffers of [16][128] floats per operand (UNPADDED: the DMA image is lane-linear, reads along the row are conflict-free
+// anyway); the DMAs of tile t + NB-1 are issued at the top of tile t into the buffer tile t-1 just left, a counted vmcnt retires
+// tile t+1 before the (raw) barrier that ends tile t.  Per thread and tile: 4 DMA instructions instead of 4 loads + 10 ds_writes.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+template <int NB>
+__global__ __launch_bounds__(NT) void gemm_v7(const float* At, const float* B, float* C, int M, int N, int K) {
+    constexpr int BK = 16, LD = 128;
+    __shared__ __attribute__((aligned(16))) float S[NB][2][BK][LD];      // one object: [buffer][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // a tile is 16 rows x 512 B = 8 pieces of 1 KiB (two rows); wave w moves pieces 2w and 2w+1 of A and of B
+    auto dma = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int kk = 2 * piece + (lane >> 5), q = (lane & 31) * 4;
+            __builtin_amdgcn_global_load_lds((glb_void*)(At + (int64_t)(k0 + kk) * M + m0 + q), (lds_void*)&S[buf][0][2 * piece][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(B + (int64_t)(k0 + kk) * N + n0 + q), (lds_void*)&S[buf][1][2 * piece][0], 16, 0, 0);
+        }
+    };
+    const int nk = K / BK;
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t)
+        if (t < nk) dma(t, t * BK);
+    // tile 0 must have landed: all but the (NB-2) younger tiles' 4 DMAs each
+    if (NB == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NB == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt % NB;
+        const int pre = kt + NB - 1;
+        if (pre < nk) dma(pre % NB, pre * BK);                            // into the buffer tile kt-1 used (all waves passed the barrier)
+        mma<BK, LD>(S[cur][0], S[cur][1], acc, wm, wn, lane, [&](int) {});
+        // retire tile kt+1 (leave the younger NB-2 tiles in flight), then let every wave finish reading tile kt
+        if (NB == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NB == 3) { if (pre < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else { if (pre < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    store_c(C, N, m0, n0, wm, wn, lane, acc);
+}
+
 int main(int argc, char** argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int per_cu = argc > 2 ? atoi(argv[2]) : 1;
@@ -384,6 +432,9 @@ int main(int argc, char** argv) {
         if (variant == 0) hipLaunchKernelGGL(gemm_v0, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 1) hipLaunchKernelGGL(gemm_v1, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 6) hipLaunchKernelGGL(gemm_v6, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
+        else if (variant == 72) hipLaunchKernelGGL(gemm_v7<2>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
+        else if (variant == 73) hipLaunchKernelGGL(gemm_v7<3>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
+        else if (variant == 74) hipLaunchKernelGGL(gemm_v7<4>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
         else if (variant == 5) hipLaunchKernelGGL(gemm_v5, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 4) hipLaunchKernelGGL(gemm_v4, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 3) hipLaunchKernelGGL(gemm_v3, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
