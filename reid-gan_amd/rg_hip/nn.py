@@ -210,6 +210,27 @@ class _BatchNorm(RGModule):
     def extra_repr(self):
         return "%d, eps=%g, momentum=%g, affine=%s" % (self.num_features, self.eps, self.momentum, self.affine)
 
+    def _flush_nbt(self):
+        n = self.__dict__.get("_nbt_pending", 0)
+        if n:
+            self.__dict__["_nbt_pending"] = 0
+            buf = self._buffers.get("num_batches_tracked")
+            if buf is not None:
+                buf += n
+
+    def __getattr__(self, name):
+        if name == "num_batches_tracked":
+            self._flush_nbt()
+        return super(_BatchNorm, self).__getattr__(name)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_nbt()
+        super(_BatchNorm, self)._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        self.__dict__["_nbt_pending"] = 0          # the loaded counter replaces whatever was pending
+        super(_BatchNorm, self)._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
         batch_stats = self.training or not self.track_running_stats
         if batch_stats:
@@ -218,7 +239,9 @@ class _BatchNorm(RGModule):
             mean, stat = ops.bn_stats(x, rm, rv, self.eps, self.momentum)
             is_var = False
             if self.track_running_stats:
-                self.num_batches_tracked += 1          # bookkeeping counter (int64 buffer)
+                # bookkeeping counter (int64 buffer): counted on the host, written to the buffer when someone looks
+                # (attribute access, state_dict) instead of one tiny device launch per layer and step
+                self.__dict__["_nbt_pending"] = self.__dict__.get("_nbt_pending", 0) + 1
         else:
             mean, stat, is_var = self.running_mean, self.running_var, True
         y = ops.bn_apply_fwd(x, mean, stat, self.weight, self.bias, residual, is_var, self.eps, act, slope)
