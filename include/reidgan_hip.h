@@ -284,6 +284,27 @@ int rg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, in
 int rg_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                 float weight_decay, int first_step, float grad_scale, rg_stream_t stream);
 
+/* ---- on-device input synthesis: the reference's per-sample PIL / scipy steps as batch kernels ---- */
+/* Pose heat maps out[N][J][H][W] from integer joint centres centers[N][J][2] = (row, col); a negative (or out-of-range)
+ * coordinate marks a missing / erased joint -> zero map.  sigma[N]: one Gaussian width per sample.
+ * mode 0: FD/reid/utils/data/preprocessor.py:114-131 (_generate_pose_map) — unit impulse -> scipy gaussian_filter(sigma,
+ *         truncate 4, mode 'reflect') -> divided by the map maximum (float64 arithmetic, float32 result);
+ * mode 1: CC/clustercontrast/utils/data/pose_utils.py:51-70 (cords_to_map) — exp(-((y-r)^2 + (x-c)^2) / (2 sigma^2)); centres
+ *         outside the image are evaluated like any other (the reference does), only INT32_MIN marks a missing joint.
+ * The random choices (erased joint, sigma) are drawn on the host in the reference's order and arrive as inputs. */
+int rg_pose_maps(const int* centers, const float* sigma, float* out, int N, int J, int H, int W, int mode,
+                 rg_stream_t stream);
+/* out[n][c][y][x] = P[n][c][top + y][left + (flip ? W-1-x : x)] with P = x[N][C][Hs][Ws] padded by `pad` pixels of
+ * pad_value[c] (NULL: 0) and params[N][3] = (flip, top, left): torchvision's Pad(pad) + RandomCrop((H, W)) +
+ * RandomHorizontalFlip of CC/examples/cluster_contrast_gan_train_usl_infomap.py:110-119, and np.flip(maps, 2) of
+ * FD/reid/utils/data/preprocessor.py:88-91 (pad 0, top = left = 0). */
+int rg_flip_pad_crop(const float* x, const int* params, const float* pad_value, float* out, int N, int C, int Hs, int Ws,
+                     int H, int W, int pad, rg_stream_t stream);
+/* RandomErasing, CC/clustercontrast/utils/data/transforms.py:52-96: x[n][c][r0:r0+h][c0:c0+w] = fill[c] in place for
+ * rects[N][4] = (r0, c0, h, w); h = 0 leaves sample n untouched; a NaN fill[c] leaves channel c untouched (the reference
+ * erases only channel 0 of non-RGB inputs). */
+int rg_erase_rects(float* x, const int* rects, const float* fill, int N, int C, int H, int W, rg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

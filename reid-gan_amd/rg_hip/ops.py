@@ -890,3 +890,46 @@ def profile_collect():
     calls = (ctypes.c_longlong * n)()
     lib.rg_profile_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(by), ctypes.addressof(calls))
     return {FAMILIES[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "calls": calls[i]} for i in range(n)}
+
+
+# ---- on-device input synthesis (SURVEY §8f rank 3) --------------------------------------------------------------
+def pose_maps(centers, sigma, height, width, mode=0):
+    """[N, J, H, W] heat maps from int32 joint centres [N, J, 2] = (row, col) (negative: missing joint) and one sigma
+    per sample.  mode 0: FD-GAN's filtered impulse / max (preprocessor.py:114-131); mode 1: plain Gaussian
+    (pose_utils.py:51-70)."""
+    if centers.dtype != torch.int32 or centers.dim() != 3 or centers.shape[2] != 2 or not centers.is_cuda:
+        raise ValueError("pose_maps: centers must be an int32 device tensor [N, J, 2]")
+    centers = centers.contiguous()
+    sigma = _chk(sigma, "sigma")
+    N, J = centers.shape[0], centers.shape[1]
+    if sigma.numel() != N:
+        raise ValueError("pose_maps: one sigma per sample expected")
+    out = torch.empty((N, J, height, width), dtype=torch.float32, device=centers.device)
+    lib.rg_pose_maps(_p(centers), _p(sigma), _p(out), N, J, height, width, mode, _stream())
+    return out
+
+
+def flip_pad_crop(x, params, out_hw, pad=0, pad_value=None):
+    """out[n, c, y, x] = padded(x)[n, c, top + y, left + (flip ? W-1-x : x)], params int32 [N, 3] = (flip, top, left)."""
+    x = _chk(x, "x")
+    if params.dtype != torch.int32 or tuple(params.shape) != (x.shape[0], 3) or not params.is_cuda:
+        raise ValueError("flip_pad_crop: params must be an int32 device tensor [N, 3]")
+    N, C, Hs, Ws = x.shape
+    H, W = out_hw
+    pad_value = _chk(pad_value, "pad_value")
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    lib.rg_flip_pad_crop(_p(x), _p(params.contiguous()), _p(pad_value), _p(out), N, C, Hs, Ws, H, W, pad, _stream())
+    return out
+
+
+def erase_rects_(x, rects, fill):
+    """in place: x[n, c, r0:r0+h, c0:c0+w] = fill[c] for rects int32 [N, 4] = (r0, c0, h, w); h = 0: untouched."""
+    x = _chk(x, "x")
+    if rects.dtype != torch.int32 or tuple(rects.shape) != (x.shape[0], 4) or not rects.is_cuda:
+        raise ValueError("erase_rects_: rects must be an int32 device tensor [N, 4]")
+    fill = _chk(fill, "fill")
+    if fill.numel() != x.shape[1]:
+        raise ValueError("erase_rects_: one fill value per channel expected")
+    N, C, H, W = x.shape
+    lib.rg_erase_rects(_p(x), _p(rects.contiguous()), _p(fill), N, C, H, W, _stream())
+    return x
