@@ -46,8 +46,15 @@ __global__ __launch_bounds__(256) void pose_maps_kernel(const int* __restrict__ 
     const double sg = (double)sigma[n];
     if (mode == 0) {
         const int r = (int)(4.0 * sg + 0.5);                 // scipy: int(truncate * sd + 0.5)
-        double wsum = 0.0;
-        for (int k = -r; k <= r; ++k) wsum += exp(-0.5 / (sg * sg) * (double)k * (double)k);
+        // kernel normalisation sum_k exp(-k^2 / 2 sigma^2), summed in scipy's order (k ascending) by one thread
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int k = -r; k <= r; ++k) acc += exp(-0.5 / (sg * sg) * (double)k * (double)k);
+            red[0] = acc;
+        }
+        __syncthreads();
+        const double wsum = red[0];
+        __syncthreads();
         for (int i = tid; i < H; i += 256) fy[i] = impulse_response(i, cy, H, r, sg, wsum);
         for (int i = tid; i < W; i += 256) fx[i] = impulse_response(i, cx, W, r, sg, wsum);
         __syncthreads();
@@ -72,11 +79,15 @@ __global__ __launch_bounds__(256) void pose_maps_kernel(const int* __restrict__ 
             o[i] = (float)(fy[y] * fx[x] * inv);
         }
     } else {
+        // exp(-(dy^2 + dx^2) / 2 sigma^2) as the product of two float64 profiles (one exp per row / column instead of
+        // one per pixel; differs from the single exp by ~1e-16 relative, invisible after the float32 rounding)
         const double inv = -1.0 / (2.0 * sg * sg);
+        for (int i = tid; i < H; i += 256) fy[i] = exp((double)(i - cy) * (double)(i - cy) * inv);
+        for (int i = tid; i < W; i += 256) fx[i] = exp((double)(i - cx) * (double)(i - cx) * inv);
+        __syncthreads();
         for (int i = tid; i < H * W; i += 256) {
             const int y = i / W, x = i - y * W;
-            const double d = (double)((y - cy) * (y - cy) + (x - cx) * (x - cx));
-            o[i] = (float)exp(d * inv);
+            o[i] = (float)(fy[y] * fx[x]);
         }
     }
 }

@@ -103,9 +103,12 @@ def test_pose_maps_full_batch_properties(dev):
     peak = maps[:, present].amax((2, 3))
     assert (peak == 1).all()                                         # divided by the map maximum
     idx = maps[:, present].flatten(2).argmax(2).cpu().numpy()
-    # the maximum sits at the landmark (up to the one-pixel pull of a reflecting border)
+    # the maximum sits at the landmark; within a few pixels of a border the reflected tail pulls it towards the border
     rows, cols = idx // 128, idx % 128
-    assert (np.abs(rows - lm[:, present, 0]) <= 1).all() and (np.abs(cols - lm[:, present, 1]) <= 1).all()
+    dr, dc = np.abs(rows - lm[:, present, 0]), np.abs(cols - lm[:, present, 1])
+    assert (dr <= 4).all() and (dc <= 4).all()
+    interior = (lm[:, present, 0] >= 20) & (lm[:, present, 0] < 236) & (lm[:, present, 1] >= 20) & (lm[:, present, 1] < 108)
+    assert (dr[interior] == 0).all() and (dc[interior] == 0).all()
     assert (maps >= 0).all() and torch.isfinite(maps).all()
     flipped = gen(lm, draws=[(None, 5, True)] * 32)[0]
     assert torch.equal(flipped, maps.flip(3))
