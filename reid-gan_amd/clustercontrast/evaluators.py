@@ -97,3 +97,9 @@ def pairwise_distance(features, query=None, gallery=None):
     xd, yd = x.float().to(dev).contiguous(), y.float().to(dev).contiguous()
     dist_m = _dist_block(xd, yd, 1.0, True)
     return dist_m.cpu(), x.numpy(), y.numpy()
+
+
+# `Evaluator`, `evaluate_all`, CMC / mAP and re-ranking are the reference's own (CPU) code: when its tree sits behind this
+# one on sys.path they are taken from there, and they call the functions above (rg_hip/overlay.py)
+from rg_hip.overlay import inherit as _rg_inherit  # noqa: E402
+_rg_inherit(globals())

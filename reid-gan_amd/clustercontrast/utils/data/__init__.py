@@ -1,1 +1,4 @@
 """Device-side pieces of cluster-contrast-reid-main/clustercontrast/utils/data that sit on the training step."""
+
+from rg_hip.overlay import extend as _rg_extend  # noqa: E402
+_rg_extend(globals(), run_init=True)       # see rg_hip/overlay.py: the reference tree may sit behind this one on sys.path

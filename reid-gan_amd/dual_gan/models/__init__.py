@@ -1,5 +1,9 @@
 """This package contains modules related to function, network architectures, and models
 (mirror of CC/dual_gan/models/__init__.py)."""
+
+from rg_hip.overlay import extend as _rg_extend  # noqa: E402
+_rg_extend(globals(), run_init=False)       # see rg_hip/overlay.py: the reference tree may sit behind this one on sys.path
+
 import importlib
 
 from .base_model import BaseModel

@@ -1,2 +1,5 @@
 """Drop-in `fdgan` package (FD-GAN-master/fdgan): networks, losses and the FDGANModel step driver on the
 MI355X HIP kernels."""
+
+from rg_hip.overlay import extend as _rg_extend  # noqa: E402
+_rg_extend(globals(), run_init=True)       # see rg_hip/overlay.py: the reference tree may sit behind this one on sys.path

@@ -1,6 +1,10 @@
 """Model registry — mirrors FD-GAN-master/reid/models/__init__.py:6-52 (names(), create())."""
 from __future__ import absolute_import
 
+from rg_hip.overlay import extend as _rg_extend  # noqa: E402
+_rg_extend(globals(), run_init=False)       # see rg_hip/overlay.py: the reference tree may sit behind this one on sys.path
+
+
 from .resnet import *  # noqa: F401,F403
 from .resnet import resnet18, resnet34, resnet50, resnet101, resnet152
 

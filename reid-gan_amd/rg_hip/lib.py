@@ -41,7 +41,8 @@ def _ctype_of(decl):
 
 def parse_header(path=HEADER_PATH):
     """Returns {name: (restype_decl, [(type_decl, arg_name), ...])} for every prototype."""
-    text = open(path).read()
+    with open(path) as f:
+        text = f.read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"//[^\n]*", " ", text)
     text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)

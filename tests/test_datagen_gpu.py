@@ -33,7 +33,7 @@ def test_fd_pose_maps_match_oracle(dev):
 
 
 def test_cords_to_map_matches_oracle(dev):
-    from clustercontrast.utils.data.pose_utils import cords_to_map, cords_to_map_batch, MISSING_VALUE
+    from clustercontrast.utils.data.device_pose import cords_to_map, cords_to_map_batch, MISSING_VALUE
     g = np.random.RandomState(3)
     cords = np.stack([g.randint(0, 128, 18), g.randint(0, 64, 18)], 1)
     cords[2] = (MISSING_VALUE, MISSING_VALUE)
