@@ -113,3 +113,25 @@ def test_dualgan_api_errors():
     with pytest.raises(TypeError):
         N.define_G(argparse.Namespace(model_gen='nope', init_type='orthogonal'), 3, 18)
     assert BF.get_norm_layer('none') is None
+
+
+def test_average_meter_interface():
+    """attribute interface the trainers' progress lines read (CC/clustercontrast/utils/meters.py)"""
+    from clustercontrast.utils.meters import AverageMeter
+    m = AverageMeter()
+    assert (m.val, m.avg, m.sum, m.count) == (0, 0, 0, 0)
+    m.update(2.0)
+    m.update(4.0, n=3)
+    assert m.val == 4.0 and m.sum == 14.0 and m.count == 4 and m.avg == 3.5
+    m.reset()
+    assert (m.val, m.avg, m.sum, m.count) == (0, 0, 0, 0)
+
+
+def test_dual_gan_registry():
+    import dual_gan.models as DM
+    from dual_gan.models.AE_model import AEModel
+    assert DM.find_model_using_name("AE") is AEModel
+    assert DM.get_option_setter("AE") == AEModel.modify_options
+    import pytest
+    with pytest.raises(ImportError):
+        DM.find_model_using_name("nope")
