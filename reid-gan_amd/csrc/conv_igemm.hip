@@ -1729,8 +1729,12 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     pl.n_tiles = rg::cdiv(Ng, kTileBN[pl.tile]);
     const int64_t nk = rg::cdiv64(Kg, BK);
     const int64_t mn = (int64_t)pl.m_tiles * pl.n_tiles;
-    int64_t want = rg::cdiv64(768, mn);   // three full rounds of 256 workgroups (measured best; the fwd cost model
-    if (want > nk / 16) want = nk / 16;   // over-splits here).  >= 16 k-tiles per split keeps partial traffic small
+    // 1024 workgroups = one full round at the kernel's 4 workgroups per CU (measured: 512 / 768 / 896 / 1024 / 1152 / 1280 /
+    // 1536 -> 71.9 / 75.2 / 75.7 / 78.5 / 75.3 / 77.7 / 76.9 TFLOP/s over the FD-GAN step's wgrad launches; the fwd cost
+    // model over-splits here)
+    static const int target_wg = getenv("RG_WGRAD_WG") ? atoi(getenv("RG_WGRAD_WG")) : 1024;
+    int64_t want = rg::cdiv64(target_wg, mn);
+    if (want > nk / 16) want = nk / 16;   // >= 16 k-tiles per split keeps partial traffic small
     if (want < 1) want = 1;
     if (want > 512) want = 512;
     while (want > 1 && want * (int64_t)M * Ng * 4 >= (1ll << 31)) --want;
