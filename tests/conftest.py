@@ -20,3 +20,14 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is built in-tree by __graft_entry__.build() / make; a fresh checkout that runs the tests first
+    builds it here (hipcc cross-compiles gfx950 without a GPU) instead of failing every import of rg_hip."""
+    lib = os.path.join(PKG, "lib", "libreidgan_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc")], check=True, stdout=subprocess.DEVNULL)
+    yield
