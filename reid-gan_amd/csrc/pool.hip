@@ -79,6 +79,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// The ResNet stem's pool (3x3 / 2, pad 1; W % 4 == 0): one thread per 4 consecutive input pixels of a row.  An input
+// pixel with even coordinate lies in one window along that axis, an odd one in two, so the 4 pixels share the 3 windows
+// q0 .. q0+2 (q0 = w0 / 2) of at most two window rows: 6 (argmax, dy) pairs are loaded once and distributed, and the row
+// is written as one float4.  Same gather form and summation order (window rows ascending, then columns) as the generic
+// kernel: bit-identical results.
+__global__ __launch_bounds__(256) void maxpool_bwd_3x3s2_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg,
+                                                                float* __restrict__ dx, int H, int W, int P, int Q) {
+    const int plane = blockIdx.y;
+    const float* gp = dy + (int64_t)plane * P * Q;
+    const unsigned char* ap = arg + (int64_t)plane * P * Q;
+    float* dxp = dx + (int64_t)plane * H * W;
+    const int W4 = W >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W4; i += gridDim.x * 256) {
+        const int h = i / W4, w0 = (i - h * W4) * 4;
+        const int q0 = w0 >> 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // window rows p with 2p - 1 <= h <= 2p + 1
+        const int p_lo = h >> 1;                 // h even: h/2 only;  h odd: (h-1)/2 and (h+1)/2
+        const int p_hi = (h + 1) >> 1;
+        for (int p = p_lo; p <= p_hi; ++p) {
+            if (p >= P) break;
+            const int r = h - (2 * p - 1);
+            float g[3];
+            int a[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int q = q0 + t;
+                const bool ok = q < Q;
+                g[t] = ok ? gp[p * Q + q] : 0.f;
+                a[t] = ok ? (int)ap[p * Q + q] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // pixel w0 + j: windows q with 2q - 1 <= w <= 2q + 1, ascending q as in the generic kernel
+                const int t_lo = j >> 1, t_hi = (j + 1) >> 1;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (t < t_lo || t > t_hi) continue;
+                    const int sidx = (w0 + j) - (2 * (q0 + t) - 1);
+                    if (a[t] == r * 3 + sidx) acc[j] += g[t];
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dxp + h * W + w0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 // one wave per (n,c) plane
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int planes,
                                                       int HW) {
@@ -175,6 +222,13 @@ extern "C" int rg_maxpool2d_bwd(const float* dy, const unsigned char* argmax, fl
     // grid.y is limited to 65535: fold the excess into z
     const int gy = planes > 65535 ? 65535 : (int)planes;
     RG_REQUIRE(planes <= 65535, "rg_maxpool2d_bwd: N*C > 65535 planes");
+    if (KH == 3 && KW == 3 && SH == 2 && SW == 2 && PH == 1 && PW == 1 && (W & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+        int g4 = rg::cdiv(H * (W >> 2), 256);
+        if (g4 > 64) g4 = 64;
+        hipLaunchKernelGGL(maxpool_bwd_3x3s2_kernel, dim3(g4, gy), dim3(256), 0, stream, dy, argmax, dx, H, W, P, Q);
+        return rg::check_launch("rg_maxpool2d_bwd");
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gx, gy), dim3(256), 0, stream, dy, argmax, dx, H, W, P, Q, KH, KW, SH, SW,
                        PH, PW);
     return rg::check_launch("rg_maxpool2d_bwd");

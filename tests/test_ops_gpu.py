@@ -228,6 +228,16 @@ def test_pooling(dev):
     y, arg = ops.maxpool2d_fwd(x.to(dev), 3, 2, 1)
     _close(y, yr, tol=0, name="maxpool")
     _close(ops.maxpool2d_bwd(dy.to(dev), arg, x.shape, 3, 2, 1), xd.grad, name="maxpool bwd")
+    # W % 4 == 0: the 4-pixels-per-thread kernel of the 3x3 / 2 stem pool (odd and even heights, ties from the ReLU)
+    for shp in ((2, 5, 18, 12), (1, 3, 7, 8), (3, 2, 32, 16)):
+        x4 = torch.randn(*shp, generator=g).relu()
+        x4d = x4.double().requires_grad_(True)
+        y4r = F.max_pool2d(x4d, 3, 2, 1)
+        dy4 = torch.randn(y4r.shape, generator=g)
+        y4r.backward(dy4.double())
+        y4, arg4 = ops.maxpool2d_fwd(x4.to(dev), 3, 2, 1)
+        _close(y4, y4r, tol=0, name="maxpool %s" % (shp,))
+        _close(ops.maxpool2d_bwd(dy4.to(dev), arg4, x4.shape, 3, 2, 1), x4d.grad, tol=1e-6, name="maxpool bwd %s" % (shp,))
     # global average
     x = torch.randn(3, 40, 8, 4, generator=g)
     xd = x.double().requires_grad_(True)
