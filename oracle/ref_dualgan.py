@@ -13,7 +13,6 @@ from the cited lines (CC/ = /root/reference/cluster-contrast-reid-main/).
 from __future__ import absolute_import
 
 import copy
-import math
 
 import torch
 import torch.nn as nn

@@ -16,7 +16,6 @@ Citations: FD/ = /root/reference/FD-GAN-master/, CC/ = /root/reference/cluster-c
 from __future__ import absolute_import
 
 import collections
-import functools
 import random
 
 import numpy as np

@@ -7,7 +7,6 @@ tuple (bn_x, F.normalize(gan_x, dim=1)) (:96-107), in eval mode the L2-normalise
 """
 from __future__ import absolute_import
 
-import torch
 from torch.nn import init
 
 from rg_hip import nn as rnn

@@ -18,7 +18,6 @@ from __future__ import absolute_import
 import itertools
 
 import torch
-from torch import nn
 
 from rg_hip import functional as RF
 from rg_hip import nn as rnn

@@ -17,7 +17,7 @@ from torch.optim import lr_scheduler
 
 from rg_hip import nn as rnn
 from rg_hip import ops
-from rg_hip.ops import ACT_LEAKY, ACT_NONE, ACT_TANH
+from rg_hip.ops import ACT_LEAKY, ACT_TANH
 from rg_hip.parallel import DataParallel
 from rg_hip.tape import RGModule, _param_list
 

@@ -8,7 +8,6 @@ the block programs of base_function.py / PTM.py.
 from __future__ import absolute_import
 
 import torch
-from torch import nn
 
 from rg_hip import nn as rnn
 from rg_hip import ops

@@ -22,7 +22,6 @@ from __future__ import absolute_import
 
 from collections import OrderedDict
 
-import torch
 
 
 class _DeferredD(object):

@@ -15,7 +15,6 @@ from __future__ import absolute_import
 
 import functools
 
-import torch
 from torch.nn import init
 from torch.optim import lr_scheduler
 

@@ -16,7 +16,6 @@ import torch
 from torch.optim import Optimizer
 
 from . import ops
-from .nn import WEIGHT_EPOCH
 
 _ALIGN = 64          # elements; keeps every view 256-byte aligned (float4 kernels, RCCL)
 

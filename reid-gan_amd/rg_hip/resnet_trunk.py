@@ -14,7 +14,6 @@ import os
 import torch
 
 from . import nn as rnn
-from . import ops
 from .ops import ACT_RELU
 from .tape import RGModule
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.test_modules_gpu import _check, _check_anchored, _check_grads_anchored, _check_l2, _rel
+from tests.test_modules_gpu import _check, _check_grads_anchored, _check_l2
 
 pytestmark = pytest.mark.gpu
 

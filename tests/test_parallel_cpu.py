@@ -4,7 +4,6 @@ all-gather used for the ClusterMemory update.  The kernels themselves are GPU-on
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -1,6 +1,6 @@
 """Throughput of the on-device input synthesis kernels at config-2 batch size, with the oracle
 (numpy / scipy, what the reference's DataLoader workers run per sample) timed beside it."""
-import os, sys, time, random
+import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "reid-gan_amd"))
 sys.path.insert(0, REPO)

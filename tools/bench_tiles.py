@@ -1,5 +1,5 @@
 """stride-2 dgrad shapes under the tile forced by RG_CONV_FORCE (read once per process): development aid."""
-import os, sys, subprocess, json
+import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reid-gan_amd"))
 import torch
 from rg_hip import ops
