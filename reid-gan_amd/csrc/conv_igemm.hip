@@ -1084,9 +1084,22 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int mt = blockIdx.x % p.m_tiles, nt = blockIdx.x / p.m_tiles;
+    // Workgroups of one split read the same slice of dy and x (every tile row shares dy rows, every tile column x columns),
+    // workgroups of different splits share nothing: with a multiple of 8 splits, split s lives entirely on XCD s % 8 (block
+    // ids are dealt round-robin over the XCDs in x-then-z order), so each slice is pulled into ONE L2 instead of all eight
+    // (measured before: 4.8x the algorithmic bytes fetched).  Otherwise: the tile remap inside each split.
+    int tile_id, split;
+    if ((gridDim.z & 7) == 0) {
+        const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7, idx = lin >> 3;
+        split = (int)(xcd + 8 * (idx / gridDim.x));
+        tile_id = (int)(idx % gridDim.x);
+    } else {
+        split = blockIdx.z;
+        tile_id = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    const int mt = tile_id % p.m_tiles, nt = tile_id / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int split = blockIdx.z;
     const rsrc_t rdy = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
 
     const int kk = tid & 15, r0 = tid >> 4;  // lanes run along the reduction (pixel) axis
@@ -1738,6 +1751,17 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     if (want < 1) want = 1;
     if (want > 512) want = 512;
     while (want > 1 && want * (int64_t)M * Ng * 4 >= (1ll << 31)) --want;
+    static const int xcd_splits = getenv("RG_WGRAD_XCD") ? atoi(getenv("RG_WGRAD_XCD")) : 1;
+    if (xcd_splits && want >= 8) {
+        // a multiple of 8 splits (see the kernel's split -> XCD mapping); trailing splits may be empty (they store zeros)
+        int64_t w8 = (want + 4) / 8 * 8;
+        while (w8 > 8 && w8 * (int64_t)M * Ng * 4 >= (1ll << 31)) w8 -= 8;
+        if (w8 * (int64_t)M * Ng * 4 < (1ll << 31) && w8 <= nk) {
+            pl.ktiles_per_split = (int)rg::cdiv64(nk, w8);
+            pl.splits = (int)w8;
+            return pl;
+        }
+    }
     pl.ktiles_per_split = (int)rg::cdiv64(nk, want);
     pl.splits = (int)rg::cdiv64(nk, pl.ktiles_per_split);
     return pl;
