@@ -19,17 +19,31 @@ from torch import nn, autograd
 
 from rg_hip import functional as RF
 from rg_hip import ops
-from rg_hip.parallel import all_gather_rows, world_size
+from rg_hip.parallel import all_gather_rows_async, world_size
 
 
 def _momentum_value(m):
     return float(m.reshape(-1)[0].item()) if isinstance(m, torch.Tensor) else float(m)
 
 
-def _gathered(inputs, targets):
-    if world_size() == 1:
-        return inputs, targets
-    return all_gather_rows(inputs), all_gather_rows(targets)
+class _Gather(object):
+    """Batch features + labels of every rank, in rank order.  Issued in the autograd Function's FORWARD (the values
+    are final there: the normalised batch features) on the process group's stream and collected right before
+    rg_cm_update in backward, so the collective hides behind the loss / dgrad instead of blocking the compute stream
+    (reference update: CC/clustercontrast/models/cm.py:22-33)."""
+    __slots__ = ("hx", "hy")
+
+    def __init__(self, inputs, targets):
+        if world_size() == 1:
+            self.hx = self.hy = None
+        else:
+            self.hx = all_gather_rows_async(inputs.detach())
+            self.hy = all_gather_rows_async(targets)
+
+    def wait(self, inputs, targets):
+        if self.hx is None:
+            return inputs, targets
+        return self.hx.wait(), self.hy.wait()
 
 
 class CM(autograd.Function):
@@ -39,6 +53,7 @@ class CM(autograd.Function):
         ctx.features = features
         ctx.momentum = _momentum_value(momentum)
         ctx.save_for_backward(inputs, targets)
+        ctx.gather = _Gather(inputs, targets)
         return ops.linear_fwd(inputs, features)
 
     @staticmethod
@@ -47,7 +62,7 @@ class CM(autograd.Function):
         grad_inputs = None
         if ctx.needs_input_grad[0]:
             grad_inputs = ops.linear_dgrad(grad_outputs, ctx.features)
-        xs, ys = _gathered(inputs, targets)
+        xs, ys = ctx.gather.wait(inputs, targets)
         ops.cm_update(xs, ys, ctx.features, ctx.momentum)           # after dgrad: it used the pre-update bank
         return grad_inputs, None, None, None
 
@@ -63,6 +78,7 @@ class CM_Hard(autograd.Function):
         ctx.features = features
         ctx.momentum = _momentum_value(momentum)
         ctx.save_for_backward(inputs, targets)
+        ctx.gather = _Gather(inputs, targets)
         return ops.linear_fwd(inputs, features)
 
     @staticmethod
@@ -71,7 +87,7 @@ class CM_Hard(autograd.Function):
         grad_inputs = None
         if ctx.needs_input_grad[0]:
             grad_inputs = ops.linear_dgrad(grad_outputs, ctx.features)
-        xs, ys = _gathered(inputs, targets)
+        xs, ys = ctx.gather.wait(inputs, targets)
         ops.cm_update(xs, ys, ctx.features, ctx.momentum, hard=True)
         return grad_inputs, None, None, None
 
@@ -88,6 +104,8 @@ class CM_gan(autograd.Function):
         ctx.gan_features = gan_features
         ctx.momentum = _momentum_value(momentum)
         ctx.save_for_backward(inputs, gan_inputs, targets)
+        ctx.gather = _Gather(inputs, targets)
+        ctx.gather_gan = _Gather(gan_inputs, targets)
         return ops.linear_fwd(inputs, features)
 
     @staticmethod
@@ -96,9 +114,9 @@ class CM_gan(autograd.Function):
         grad_inputs = None
         if ctx.needs_input_grad[0]:
             grad_inputs = ops.linear_dgrad(grad_outputs, ctx.features)
-        xs, ys = _gathered(inputs, targets)
+        xs, ys = ctx.gather.wait(inputs, targets)
         ops.cm_update(xs, ys, ctx.features, ctx.momentum)
-        gs, _ = _gathered(gan_inputs, targets)
+        gs, _ = ctx.gather_gan.wait(gan_inputs, targets)
         ops.cm_update(gs, ys, ctx.gan_features, ctx.momentum, normalize_eps=True)     # F.normalize flavour (:103)
         return grad_inputs, None, None, None, None, None
 
@@ -148,7 +166,9 @@ class ClusterMemory_Gradient(nn.Module, ABC):
         from rg_hip import optim as roptim
         self.trainable_clusters = clusters.detach().clone().requires_grad_(True)
         self.optimizer_cluster = roptim.SGD([self.trainable_clusters], lr=cluster_lr)
-        self.normed_clusters = ops.l2norm_rows_fwd(self.trainable_clusters.detach())[0]
+        # attached, as the reference's F.normalize(self.trainable_clusters) (:150,193): losses built on
+        # `normed_clusters` reach trainable_clusters.grad; forward() itself detaches it (:163)
+        self.normed_clusters = RF.normalize_rows(self.trainable_clusters)
 
     def forward(self, inputs, targets, ex_f=None):
         inputs = RF.normalize_rows(inputs)
@@ -164,11 +184,15 @@ class ClusterMemory_Gradient(nn.Module, ABC):
 
     def update_clusters(self, p_ids, eps=1e-16):
         g = self.trainable_clusters.grad
+        if g is None:
+            raise RuntimeError("ClusterMemory_Gradient.update_clusters: trainable_clusters has no gradient — back-"
+                               "propagate a loss built on `normed_clusters` (the forward() logits are detached, "
+                               "CC/clustercontrast/models/cm.py:163) before calling it")
         ids = torch.as_tensor(p_ids, dtype=torch.int64).to(g.device).reshape(-1).contiguous()
         ops.normalize_listed_rows(g, ids, eps)
         self.optimizer_cluster.step()
         self.optimizer_cluster.zero_grad()
-        self.normed_clusters = ops.l2norm_rows_fwd(self.trainable_clusters.detach())[0]
+        self.normed_clusters = RF.normalize_rows(self.trainable_clusters)
 
 
 class _MatmulT(autograd.Function):

@@ -42,10 +42,12 @@ class _ReducerCache(object):
     def __init__(self):
         self._r = {}
 
-    def get(self, optimizer):
+    def get(self, optimizer, modules=None):
+        """`modules`: the networks this optimizer trains — rank 0's parameters and buffers are broadcast once when the
+        reducer is created, so user-built replicas need not share a seed (rg_hip.parallel.GradReducer)."""
         r = self._r.get(id(optimizer))
         if r is None:
-            r = self._r[id(optimizer)] = GradReducer(optimizer)
+            r = self._r[id(optimizer)] = GradReducer(optimizer, modules=modules)
         return r
 
 
@@ -98,7 +100,7 @@ class ClusterContrastTrainer(object):
         loss = RF.weighted_mean(self.memory(f_out, labels))
         optimizer.zero_grad()
         loss.backward()
-        self._reducers.get(optimizer).reduce()
+        self._reducers.get(optimizer, self.encoder).reduce()
         optimizer.step()
         return loss.detach()
 
@@ -160,7 +162,7 @@ class ClusterContrastWithGANTrainer(object):
                 loss = RF.weighted_mean(loss_ori)
                 optimizer.zero_grad()
                 loss.backward()
-                self._reducers.get(optimizer).reduce()
+                self._reducers.get(optimizer, self.encoder).reduce()
                 optimizer.step()
                 loss = loss.detach()
 
@@ -211,7 +213,7 @@ class ClusterContrastWithGANTrainer(object):
         gan.optimizer_G.zero_grad()
         optimizer.zero_grad()
         loss.backward()
-        self._reducers.get(optimizer).reduce()
+        self._reducers.get(optimizer, self.encoder).reduce()
         gan.optimizer_G.step()
         optimizer.step()
         return loss.detach()

@@ -1317,6 +1317,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     out[m * crs + (int64_t)c * RS + rs] = s;
 }
 
+// algorithmic HBM bytes of one conv launch: one read of each operand + one write of the result (fp32)
+#define ALG_BYTES (4.0 * ((double)N * C * H * W + (double)K * C * KH * KW + (double)N * K * P * Q))
+
 static bool fits_buffer(int64_t elems) { return elems > 0 && elems * 4 < (1ll << 31); }
 
 static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW,
@@ -1515,7 +1518,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
         if (workspace && need <= workspace_bytes) {
             ThinP t;
             thin_fill(t, x, w, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
-            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * (double)p.Ng * p.Kg);
+            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * (double)p.Ng * p.Kg, ALG_BYTES);
             const dim3 grid(rg::cdiv(p.Ng, 256), slices);
             if (KH == 4) hipLaunchKernelGGL((conv_fwd_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
             else hipLaunchKernelGGL((conv_fwd_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
@@ -1544,7 +1547,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = (unsigned)need;
-    rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
+    rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
     const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
     RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH);
     if (pl.splits > 1) {
@@ -1620,7 +1623,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
             if (dp.cls[i].Ngc > nmax) nmax = dp.cls[i].Ngc;
         p.Ng = nmax;
         p.Kg = K * KH * KW;
-        rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops);
+        rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
         bool few_taps = C <= 3;
         int gmax = 0;
         for (int i = 0; i < SH * SW; ++i) {
@@ -1688,7 +1691,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = (unsigned)need;
-    rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops);
+    rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
     RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
     if (pl.splits > 1) {
@@ -1795,7 +1798,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         if (workspace && need_thin <= workspace_bytes) {
             ThinP t;
             thin_fill(t, x, dy, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
-            rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * (double)p.Ng * p.Kg);
+            rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * (double)p.Ng * p.Kg, ALG_BYTES);
             const dim3 grid(C, slices);
             if (KH == 4) hipLaunchKernelGGL((conv_wgrad_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
             else hipLaunchKernelGGL((conv_wgrad_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
@@ -1826,7 +1829,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     p.y_bytes = via_ws ? (unsigned)need : (unsigned)((int64_t)K * C * KH * KW * 4);
     const dim3 grid(p.m_tiles * p.n_tiles, 1, pl.splits);
     {
-        rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg);
+        rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
         const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
         const bool veca = al && ((P * Q) % 4 == 0);
         const bool vec = veca && KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0;

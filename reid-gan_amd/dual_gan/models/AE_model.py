@@ -105,8 +105,8 @@ class AEModel(BaseModel):
                                            lr=opt.gan_lr * opt.ratio_g2d, betas=(opt.beta1, 0.999))
             self.optimizers.append(self.optimizer_D)
             self.schedulers = [base_function.get_scheduler(optimizer, opt) for optimizer in self.optimizers]
-            self._red_G = GradReducer(self.optimizer_G)
-            self._red_D = GradReducer(self.optimizer_D)
+            self._red_G = GradReducer(self.optimizer_G, modules=[self.net_G])
+            self._red_D = GradReducer(self.optimizer_D, modules=[self.net_D])
             _wrap_step(self.optimizer_G, self._red_G)
             _wrap_step(self.optimizer_D, self._red_D)
         else:

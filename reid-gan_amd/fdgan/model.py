@@ -161,7 +161,11 @@ class FDGANModel(object):
         for optimizer in self.optimizers:
             self.schedulers.append(get_scheduler(optimizer, opt))
         # data-parallel gradient reduction (no-op unless torch.distributed is initialised)
-        self.reducers = [GradReducer(o) for o in self.optimizers]
+        # (rank 0's parameters and buffers are broadcast once here, as DataParallel's replicate() does on every call)
+        g_nets = [self.net_G] + ([self.net_E] if opt.stage == 2 else [])
+        self.reducers = [GradReducer(self.optimizer_G, modules=g_nets),
+                         GradReducer(self.optimizer_Di, modules=[self.net_Di]),
+                         GradReducer(self.optimizer_Dp, modules=[self.net_Dp])]
         if self.reducers[0].active():
             g_params = list(self.net_G.parameters())
             self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_params)

@@ -437,9 +437,14 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
         elif need_sum:
             sg = ops.act_bwd_sum(dy, None, ACT_NONE, need_g=False, need_sum=True, out_sum=ob)[1]
     dbeta = None
+    dbeta_late = False
     if want_b:
         dbeta = sg if sg is not None else (ob if ob is not None else torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device))
-        tape.add_grad(bn.bias, dbeta)
+        # with fused sums dbeta is WRITTEN by finish() on the side stream: register it only after that launch is
+        # enqueued, so an accumulating add_grad (second backward of the pair in one tape) reads finished values
+        dbeta_late = part is not None and (want_w or want_g)
+        if not dbeta_late:
+            tape.add_grad(bn.bias, dbeta)
     if want_w or want_g:
         w = conv.weight.detach()
         og = tape.grad_out(bn.weight) if want_g else None
@@ -454,6 +459,8 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
             tape.add_grad(conv.weight, dw)
         if want_g:
             tape.add_grad(bn.weight, dgamma)
+        if dbeta_late:
+            tape.add_grad(bn.bias, dbeta)
     dx = None
     if need_dx:
         dx = ops.conv2d_dgrad(g, f.w_scaled, x.shape[2:], conv.stride, conv.padding, residual=residual,

@@ -136,6 +136,31 @@ class _FlatOptimizer(Optimizer):
         for p in self._arena.params:
             p.grad = None
 
+    # ---- checkpointing: torch.optim's per-parameter layout built from the flat moment buffers ------------------
+    def state_dict(self):
+        """{'state': {index: {...per-parameter tensors...}}, 'param_groups': [...]} as torch.optim returns it (the flat
+        moment buffers are sliced per parameter), so a resume restores moments / momentum and step counts."""
+        a = self._arena
+        packed = super(_FlatOptimizer, self).state_dict()
+        state = {}
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            entry = self._export_param_state(i, o, p)
+            if entry is not None:
+                state[i] = entry
+        packed["state"] = state
+        return packed
+
+    def load_state_dict(self, state_dict):
+        a = self._arena
+        state = state_dict.get("state", {})
+        super(_FlatOptimizer, self).load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        for k, entry in state.items():
+            i = int(k)
+            if not 0 <= i < len(a.params):
+                raise ValueError("rg_hip.optim: optimizer state refers to parameter %d of %d" % (i, len(a.params)))
+            self._import_param_state(i, a.offsets[i], a.params[i], entry)
+        self._seg_cache = None
+
 
 class Adam(_FlatOptimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_scale=1.0):
@@ -151,6 +176,19 @@ class Adam(_FlatOptimizer):
         """cached runs stay valid while every member of a run still has the run's step count"""
         st = self._steps
         return all(st[m[0]] == st[m[-1]] for _, _, m, _ in segs)
+
+    def _export_param_state(self, i, o, p):
+        if self._steps[i] == 0:
+            return None
+        n = p.numel()
+        return {"step": torch.tensor(float(self._steps[i])), "exp_avg": self._m[o:o + n].view(p.shape).clone(),
+                "exp_avg_sq": self._v[o:o + n].view(p.shape).clone()}
+
+    def _import_param_state(self, i, o, p, entry):
+        n = p.numel()
+        self._steps[i] = int(entry["step"])
+        self._m[o:o + n].copy_(entry["exp_avg"].reshape(-1))
+        self._v[o:o + n].copy_(entry["exp_avg_sq"].reshape(-1))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -188,6 +226,20 @@ class SGD(_FlatOptimizer):
     def _uniform_state(self, segs):
         st = self._started
         return all(st[m[0]] == st[m[-1]] for _, _, m, _ in segs)
+
+    def _export_param_state(self, i, o, p):
+        if not self._started[i]:
+            return None
+        n = p.numel()
+        return {"momentum_buffer": self._buf[o:o + n].view(p.shape).clone()}
+
+    def _import_param_state(self, i, o, p, entry):
+        buf = entry.get("momentum_buffer")
+        if buf is None:
+            self._started[i] = False
+            return
+        self._started[i] = True
+        self._buf[o:o + p.numel()].copy_(buf.reshape(-1))
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -36,7 +36,11 @@ def world_size():
 class GradReducer(object):
     """All-reduce (sum) of an optimizer's gradient arena; averaging happens in the optimizer kernel."""
 
-    def __init__(self, optimizer, bucket_mb=64, group=None):
+    def __init__(self, optimizer, bucket_mb=64, group=None, modules=None, broadcast=True):
+        """`modules`: the networks whose parameters live in the optimizer's arena; their buffers (BatchNorm running
+        statistics, spectral-norm u / v) are broadcast from rank 0 together with the parameter arena when the reducer
+        becomes active, so replicas start identical whatever seed each rank built its networks with (the reference's
+        DataParallel re-broadcasts rank 0's parameters and buffers on every forward call)."""
         self.optimizer = optimizer
         self.arena = getattr(optimizer, "_arena", None)
         self.group = group
@@ -45,6 +49,31 @@ class GradReducer(object):
         self._done = []          # element ranges already launched in this round
         if self.active():
             optimizer.grad_scale = 1.0 / world_size()
+            if broadcast:
+                self.broadcast_state(modules)
+
+    def broadcast_state(self, modules=None):
+        """rank 0's parameter arena (one collective per `bucket_mb` chunk) and the given modules' float / integer
+        buffers to every rank."""
+        if not self.active():
+            return
+        flat = self.arena.flat
+        pos = 0
+        while pos < flat.numel():
+            end = min(flat.numel(), pos + self.bucket_elems)
+            dist.broadcast(flat[pos:end], src=0, group=self.group)
+            pos = end
+        if modules is None:
+            return
+        if isinstance(modules, nn.Module):
+            modules = [modules]
+        seen = set()
+        for m in modules:
+            for b in m.buffers():
+                if b is None or id(b) in seen or b.numel() == 0:
+                    continue
+                seen.add(id(b))
+                dist.broadcast(b.data, src=0, group=self.group)
 
     def active(self):
         # RG_FORCE_REDUCE=1 exercises the collective path on a single rank (RCCL init, side stream, waits)
@@ -61,9 +90,14 @@ class GradReducer(object):
         out, cur = [], None
         for i in idx:
             p, o = a.params[i], a.offsets[i]
-            if p.grad is None or p.grad.data_ptr() != p._rg_grad.data_ptr():
+            if p.grad is None:
                 cur = None
                 continue
+            if p.grad.data_ptr() != p._rg_grad.data_ptr():
+                # a gradient that is not the arena view would silently miss the all-reduce: replicas would diverge
+                raise RuntimeError("GradReducer: parameter %d (shape %s) has a gradient outside the optimizer's "
+                                   "gradient arena; write it through p._rg_grad (rg_hip.optim._have() does this "
+                                   "for stock-autograd gradients before the step)" % (i, tuple(p.shape)))
             end = o + p.numel()
             if any(s <= o < e for s, e in self._done):
                 cur = None
@@ -100,6 +134,31 @@ class GradReducer(object):
     def reduce(self):
         self.reduce_async(None)
         self.wait()
+
+
+class GatherHandle(object):
+    """In-flight all_gather_rows_async: `wait()` returns the gathered tensor (rank order)."""
+
+    def __init__(self, out, work):
+        self.out, self.work = out, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def all_gather_rows_async(x, group=None):
+    """Issue the gather now (it runs on the process group's stream behind the work already queued on the current
+    stream) and collect it later: ClusterMemory issues it in forward and waits right before the centroid update in
+    backward, so the collective overlaps the loss and the whole encoder backward set-up."""
+    w = world_size()
+    if w == 1:
+        return GatherHandle(x, None)
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    work = dist.all_gather_into_tensor(out, x.contiguous(), group=group, async_op=True)
+    return GatherHandle(out, work)
 
 
 def all_gather_rows(x, group=None):

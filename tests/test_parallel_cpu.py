@@ -122,3 +122,132 @@ def test_arena_views_alias_parameters():
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     net.load_state_dict(sd)                           # in-place copy keeps the views
     assert next(net.parameters()).data_ptr() == arena.flat.data_ptr()
+
+
+# ---- replicas start identical: rank 0's parameters + buffers are broadcast when the reducer becomes active --------
+def _bcast_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                         # DIFFERENT replicas per rank, as a user script may build them
+        net = torch.nn.Sequential(torch.nn.Linear(9, 6), torch.nn.BatchNorm1d(6), torch.nn.Linear(6, 2))
+        net[1].running_mean.fill_(float(rank) + 0.5)
+        net[1].num_batches_tracked.fill_(7 + rank)
+        arena = Arena(list(net.parameters()))
+        opt = _FakeOptimizer(arena)
+        GradReducer(opt, bucket_mb=0.0001, modules=[net])     # tiny chunks: several broadcasts
+        flat = arena.flat.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same_params = all(torch.equal(g, gathered[0]) for g in gathered)
+        q.put((rank, same_params, float(net[1].running_mean[0]), int(net[1].num_batches_tracked),
+               float(next(net.parameters()).reshape(-1)[0]), float(arena.flat[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_makes_replicas_identical_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same_params, rm, nbt, p0, a0 in res:
+        assert same_params
+        assert rm == 0.5 and nbt == 7                 # rank 0's buffers everywhere
+        assert p0 == a0                               # module parameters are still views of the arena
+    assert res[0][4] == res[1][4]
+
+
+def _outside_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = torch.nn.Linear(4, 4)
+        arena = Arena(list(net.parameters()))
+        red = GradReducer(_FakeOptimizer(arena))
+        net(torch.ones(2, 4)).sum().backward()        # stock autograd: .grad is NOT the arena view
+        try:
+            red.reduce()
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_raises_on_gradient_outside_arena_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_outside_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, msg in res:
+        assert "outside the optimizer's gradient arena" in msg, msg
+
+
+# ---- ClusterMemory under data parallelism: gather in forward, identical ordered update on every rank -------------
+def _cpu_cm_update(inputs, targets, features, momentum, hard=False, normalize_eps=False):
+    """CPU stand-in for rg_cm_update with the reference's loop (CC/clustercontrast/models/cm.py:29-31)."""
+    assert not hard
+    for x, y in zip(inputs, targets):
+        features[y] = momentum * features[y] + (1.0 - momentum) * x
+        features[y] /= features[y].norm()
+    return features
+
+
+def _cm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rg_hip import ops
+        import clustercontrast.models.cm as CMM
+        ops.linear_fwd = lambda x, w, bias=None: x @ w.t()          # CPU stand-ins for the HIP kernels (test only)
+        ops.linear_dgrad = lambda dy, w: dy @ w
+        ops.cm_update = _cpu_cm_update
+        g = torch.Generator().manual_seed(3)
+        B, D, K = 6, 16, 5
+        bank0 = torch.nn.functional.normalize(torch.randn(K, D, generator=g), dim=1)
+        x_all = torch.nn.functional.normalize(torch.randn(B * world, D, generator=g), dim=1)
+        y_all = torch.tensor([0, 3, 3, 1, 0, 3, 2, 2, 3, 0, 1, 3])[:B * world]       # repeated labels across ranks
+        bank = bank0.clone()
+        xs = x_all[B * rank:B * (rank + 1)].clone().requires_grad_(True)
+        ys = y_all[B * rank:B * (rank + 1)]
+        out = CMM.cm(xs, ys, bank, 0.2)
+        out.sum().backward()
+        # single-process reference on the global batch in rank order
+        ref = _cpu_cm_update(x_all, y_all, bank0.clone(), 0.2)
+        grad_ref = torch.ones(B, K) @ bank0
+        q.put((rank, (bank - ref).abs().max().item(), (xs.grad - grad_ref).abs().max().item(), bank.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cluster_memory_gather_and_ordered_update_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, bank_err, grad_err, _ in res:
+        assert bank_err == 0.0, (rank, bank_err)      # every replica applied the same updates in the same order
+        assert grad_err < 1e-6, (rank, grad_err)      # the input gradient used the PRE-update bank and stays local
+    assert torch.equal(res[0][3], res[1][3])
