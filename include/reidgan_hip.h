@@ -42,7 +42,7 @@ const char* rg_last_error(void);
 int rg_version(void);
 
 /* ---- per-family launch profiler (HIP events on the launch stream; used by bench.py) ---------- */
-#define RG_FAMILY_COUNT 10 /* conv_fwd, conv_dgrad, conv_wgrad, norm, eltwise, pool, loss, cm, optim, misc */
+#define RG_FAMILY_COUNT 11 /* conv_fwd, conv_dgrad, conv_wgrad, norm, eltwise, pool, loss, cm, optim, misc, conv_f8 */
 int rg_family_count(void);
 int rg_profile_enable(int on);
 int rg_profile_reset(void);
@@ -154,6 +154,46 @@ int rg_affine_relu_mean_fwd(const float* x, float* loss, int64_t n, float a, flo
                             size_t workspace_bytes, rg_stream_t stream);
 int rg_affine_relu_mean_bwd(const float* x, const float* grad_out, float* dx, int64_t n, float a, float b, int clamp,
                             float grad_scale, rg_stream_t stream);
+
+/* ---- FP8 convolution family (BASELINE config 5: "dual_gan two-generator path, fp8 MFMA convs") ------------------
+ * Replaces, at reduced precision, the cuDNN work behind the nn.Conv2d / nn.ConvTranspose2d layers of the dual_gan
+ * generators and discriminator (CC/dual_gan/models/base_function.py:236-443, networks.py:165-275,917-955), which the
+ * reference runs in fp32.  OCP e4m3 for activations and filters, e5m2 for gradients, one scale per tensor, fp32
+ * accumulation on v_mfma_f32_32x32x16_{fp8,bf8}_{fp8,bf8}; outputs are fp32 NCHW like every other entry point.
+ *
+ * Scaling state of one tensor: float[4] device memory {amax in use, amax being collected, dequantisation scale = amax in
+ * use / format max, format max (448 e4m3 / 57344 e5m2; written once by the caller)}.  rg_f8_quantize scales by
+ * format max / state[0], clamps, converts and collects max|x| into state[1]; rg_f8_roll_scales makes the collected
+ * values current for `count` consecutive states (delayed scaling: once per step); rg_f8_amax followed by a roll gives
+ * just-in-time scaling.  fmt: 0 = e4m3, 1 = e5m2. */
+int rg_f8_amax(const float* x, int64_t n, float* state, rg_stream_t stream);
+int rg_f8_roll_scales(float* states, int count, rg_stream_t stream);
+/* out[b][l][r] (one byte each, r padded with zeros to a multiple of 16) = fp8(in[b*bs + r*rs + l]): the transposing
+ * quantiser behind every operand layout; scale_out (one device float, may be NULL) receives the dequantisation scale this
+ * call used, which is what the GEMMs below take as sx / sw / sdy (a layer's state may be re-scaled for another tensor
+ * before the backward pass reads this one) —  activations [N][C][HW] -> [N][HW][Cp] (b = n, r = c) for the forward / data
+ * gradient and -> [C][HW][Np] (b = c, r = n) for the weight gradient; filters [K][C][RS] -> [K][RS][Cp] and [C][RS][Kp] */
+int rg_f8_quantize(const float* in, void* out, float* state, float* scale_out, int fmt, int B, int R, int L, int64_t bs,
+                   int64_t rs, rg_stream_t stream);
+/* y = act(sx*sw * conv(xq, wq) + shift[k] + residual); xq [N][H*W][Cp], wq [K][KH*KW][Cp] (e4m3), sx / sw: the quantiser's scale_out of each operand */
+int rg_conv2d_f8_fwd(const void* xq, const void* wq, const float* sx, const float* sw, int fmt_x, float* y, int N, int C,
+                     int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* shift,
+                     const float* residual, int act, float slope, rg_stream_t stream);
+/* dx (or the forward of ConvTranspose2d) from dyq [N][P*Q][Kp] and the filters as [C][KH*KW][Kp]; stride <= 2 */
+int rg_conv2d_f8_dgrad(const void* dyq, const void* wq_t, const float* sdy, const float* sw, int fmt_dy, float* dx, int N,
+                       int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
+                       const float* shift, const float* residual, int act, float slope, rg_stream_t stream);
+/* dw[K][C][KH][KW] from the batch-contiguous layouts xq [C][H*W][Np], dyq [K][P*Q][Np]; split over the pixels, partials in
+ * the workspace, summed in fixed order */
+size_t rg_conv2d_f8_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
+int rg_conv2d_f8_wgrad(const void* xq, const void* dyq, const float* sx, const float* sdy, int fmt_x, int fmt_dy, float* dw,
+                       int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
+                       void* workspace, size_t workspace_bytes, rg_stream_t stream);
+
+/* WGAN-GP penalty terms of cal_gradient_penalty, CC/dual_gan/models/external_function.py:100-101, per sample row r of
+ * grads[rows][D] with g = grads[r] + 1e-16: pen[r] = scale * (|g|_2 - constant)^2, v[r][:] = d pen[r] / d grads[r] */
+int rg_grad_penalty_rows(const float* grads, float* pen, float* v, int rows, int D, float constant, float scale,
+                         rg_stream_t stream);
 
 /* ---- pseudo-labelling front half / evaluation distances ------------------------------ */
 /* faiss IndexFlatIP.search of CC/clustercontrast/utils/infomap_cluster.py:51-78 on a similarity block s[rows][cols]

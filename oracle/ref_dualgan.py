@@ -485,3 +485,212 @@ def synth_dualgan_inputs(n, h=128, w=64, pose_nc=18, seed=0, sigma=6.0, p_missin
     ps = torch.exp(-((yy - y0) ** 2 + (xx - x0) ** 2) / (2 * sigma ** 2))
     keep = (torch.rand(n, pose_nc, 1, 1, generator=g) >= p_missing).float()
     return {'Xs': xs, 'Ps': ps * keep}
+
+
+# =====================================================================================================================
+# DPTNModel path (BASELINE config 5): GAN objectives, gradient penalty, VGG perceptual / style loss, the step driver
+# =====================================================================================================================
+def o_ganloss(pred, target_is_real, is_disc, mode, real_label=1.0, fake_label=0.0):
+    """CC/dual_gan/models/external_function.py:46-69 for every gan_mode."""
+    if mode in ('lsgan', 'vanilla'):
+        labels = torch.full_like(pred, real_label if target_is_real else fake_label)
+        if mode == 'lsgan':
+            loss = (pred - labels) ** 2                              # MSELoss(reduction='none') (:35)
+            return loss.mean() if is_disc else loss
+        loss = F.binary_cross_entropy_with_logits(pred, labels)      # BCEWithLogitsLoss() is already a mean (:38)
+        return loss.mean() if is_disc else loss
+    if mode in ('hinge', 'wgangp'):
+        if is_disc:
+            if target_is_real:
+                pred = -pred
+            return F.relu(1 + pred).mean() if mode == 'hinge' else pred.mean()
+        return -pred.mean()
+    raise NotImplementedError('gan mode %s not implemented' % mode)
+
+
+def o_cal_gradient_penalty(netD, real, fake, alpha, constant=1.0, lambda_gp=10.0):
+    """external_function.py:72-104, type='mixed'; `alpha` [B, 1] is the torch.rand draw of :89 passed in explicitly."""
+    a = alpha.expand(real.shape[0], real.nelement() // real.shape[0]).contiguous().view(*real.shape)
+    inter = (a * real + (1 - a) * fake).detach().requires_grad_(True)
+    out = netD(inter)
+    grads = torch.autograd.grad(outputs=out, inputs=inter, grad_outputs=torch.ones_like(out), create_graph=True,
+                                retain_graph=True, only_inputs=True)[0].view(real.size(0), -1)
+    gp = (((grads + 1e-16).norm(2, dim=1) - constant) ** 2).mean() * lambda_gp
+    return gp, grads
+
+
+def o_tv_vgg19_features():
+    """torchvision.models.vgg19().features (configuration 'E', no batch norm): 16 conv3x3(pad 1)+ReLU(inplace) in groups
+    of 2, 2, 4, 4, 4 separated by MaxPool2d(2, 2) — 37 modules, indices as external_function.py:250-296 slices them.
+    THIRD-PARTY RESTATEMENT: torchvision is not installed here (version unpinned in the reference, CC/setup.py:11); the
+    architecture is the published VGG-19 (Simonyan & Zisserman 2014, table 1 column E).  Parity unpinned for this function;
+    everything the reference builds on top of it (VGG19 wrapper, VGGLoss) is pinned through it."""
+    cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+    layers, cin = [], 3
+    for v in cfg:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+_VGG_SLICES = [('relu1_1', 0, 2), ('relu1_2', 2, 4), ('relu2_1', 4, 7), ('relu2_2', 7, 9), ('relu3_1', 9, 12),
+               ('relu3_2', 12, 14), ('relu3_3', 14, 16), ('relu3_4', 16, 18), ('relu4_1', 18, 21), ('relu4_2', 21, 23),
+               ('relu4_3', 23, 25), ('relu4_4', 25, 27), ('relu5_1', 27, 30), ('relu5_2', 30, 32), ('relu5_3', 32, 34),
+               ('relu5_4', 34, 36)]
+
+
+class OVGG19(nn.Module):
+    """external_function.py:226-347: the feature stack cut into 16 named slices, parameters frozen."""
+
+    def __init__(self, features=None):
+        super(OVGG19, self).__init__()
+        features = o_tv_vgg19_features() if features is None else features
+        for name, a, b in _VGG_SLICES:
+            seq = nn.Sequential()
+            for x in range(a, b):
+                seq.add_module(str(x), features[x])
+            setattr(self, name, seq)
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        out = {}
+        for name, _, _ in _VGG_SLICES:
+            x = getattr(self, name)(x)
+            out[name] = x
+        return out
+
+
+def o_gram(x):
+    b, ch, h, w = x.size()
+    f = x.view(b, ch, w * h)
+    return f.bmm(f.transpose(1, 2)) / (h * w * ch)
+
+
+class OVGGLoss(nn.Module):
+    """external_function.py:107-147 -> (content_loss, style_loss)."""
+
+    def __init__(self, vgg=None, weights=(1.0, 1.0, 1.0, 1.0, 1.0)):
+        super(OVGGLoss, self).__init__()
+        self.vgg = OVGG19() if vgg is None else vgg
+        self.weights = list(weights)
+
+    def forward(self, x, y):
+        xv, yv = self.vgg(x), self.vgg(y)
+        content = 0.0
+        for w, k in zip(self.weights, ('relu1_1', 'relu2_1', 'relu3_1', 'relu4_1', 'relu5_1')):
+            content = content + w * F.l1_loss(xv[k], yv[k])
+        style = 0.0
+        for k in ('relu2_2', 'relu3_4', 'relu4_4', 'relu5_2'):
+            style = style + F.l1_loss(o_gram(xv[k]), o_gram(yv[k]))
+        return content, style
+
+
+def o_seed_vgg(vgg, seed=7):
+    """seeded stand-in for the ImageNet weights (a download): He-normal filters, small biases"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in vgg.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.weight[0].numel()
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
+    return vgg
+
+
+class ODPTNModel(object):
+    """DPTNModel training side, CC/dual_gan/models/DPTN_model.py:44-107 (construction), :135-137 (forward), :159-182
+    (backward_D_basic / backward_D), :184-214 (backward_G_basic / backward_G), :216-225 (optimize_parameters).
+    `vgg=None` drops the perceptual / style terms (the run configuration of BASELINE config 5: no ImageNet weights)."""
+
+    def __init__(self, net_G=None, net_D=None, gan_mode='hinge', gan_lr=2e-4, beta1=0.5, ratio_g2d=0.1, lambda_rec=2.0,
+                 lambda_g=5.0, lambda_style=500.0, lambda_content=0.5, t_s_ratio=0.8, dis_layers=3, vgg=None):
+        if net_G is None:
+            net_G = o_init_weights(ODPTNGenerator(3, 18, 64, 512, 3, 'instance', 3, 3, 2, 2, 2))        # :51-53
+        if net_D is None:
+            net_D = o_init_weights(OResDiscriminator(3, 32, 128, dis_layers, True))                       # :63
+        self.net_G, self.net_D = net_G, net_D
+        self.gan_mode, self.t_s_ratio = gan_mode, t_s_ratio
+        self.lambda_rec, self.lambda_g = lambda_rec, lambda_g
+        self.lambda_style, self.lambda_content = lambda_style, lambda_content
+        self.vgg = vgg
+        self.optimizer_G = torch.optim.Adam(net_G.parameters(), lr=gan_lr, betas=(beta1, 0.999))
+        self.optimizer_D = torch.optim.Adam(net_D.parameters(), lr=gan_lr * ratio_g2d, betas=(beta1, 0.999))
+        self.gp_alpha = None                   # wgangp: explicit interpolation draw for the next backward_D
+
+    def set_input(self, inputs):
+        self.source_image, self.source_pose = inputs['Xs'], inputs['Ps']
+        self.target_image, self.target_pose = inputs['Xt'], inputs['Pt']
+
+    def forward(self):
+        self.fake_image_t, self.fake_image_s = self.net_G(self.source_image, self.source_pose, self.target_pose)
+
+    def backward_D(self):
+        for p in self.net_D.parameters():
+            p.requires_grad = True
+        real = o_ganloss(self.net_D(self.target_image), True, True, self.gan_mode)
+        fake = o_ganloss(self.net_D(self.fake_image_t.detach()), False, True, self.gan_mode)
+        loss = (real + fake) * 0.5
+        if self.gan_mode == 'wgangp':
+            alpha = self.gp_alpha if self.gp_alpha is not None else torch.rand(self.target_image.shape[0], 1)
+            gp, _ = o_cal_gradient_penalty(self.net_D, self.target_image, self.fake_image_t.detach(), alpha)
+            loss = loss + gp
+        self.loss_dis_img_gen_t = loss
+        loss.backward()
+
+    def _g_basic(self, fake, target, use_d):
+        app = F.l1_loss(fake, target) * self.lambda_rec
+        ad = None
+        if use_d:
+            for p in self.net_D.parameters():
+                p.requires_grad = False
+            ad = o_ganloss(self.net_D(fake), True, False, self.gan_mode) * self.lambda_g
+        if self.vgg is not None:
+            content, style = self.vgg(fake, target)
+            style, content = style * self.lambda_style, content * self.lambda_content
+        else:
+            style = content = torch.zeros(())
+        return app, ad, style, content
+
+    def backward_G(self):
+        for p in self.net_D.parameters():
+            p.requires_grad = True
+        self.loss_app_gen_t, self.loss_ad_gen_t, self.loss_style_gen_t, self.loss_content_gen_t = \
+            self._g_basic(self.fake_image_t, self.target_image, True)
+        self.loss_app_gen_s, _, self.loss_style_gen_s, self.loss_content_gen_s = \
+            self._g_basic(self.fake_image_s, self.source_image, False)
+        r = self.t_s_ratio
+        G_loss = (r * (self.loss_app_gen_t + self.loss_style_gen_t + self.loss_content_gen_t)
+                  + (1 - r) * (self.loss_app_gen_s + self.loss_style_gen_s + self.loss_content_gen_s) + self.loss_ad_gen_t)
+        G_loss.backward()                      # lsgan: loss_ad_gen_t is a map -> RuntimeError, as in the reference
+        for p in self.net_D.parameters():
+            p.requires_grad = True
+
+    def optimize_parameters(self):
+        self.forward()
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.optimizer_D.step()
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.optimizer_G.step()
+
+    def step(self, inputs):
+        self.set_input(inputs)
+        self.optimize_parameters()
+        return self.get_current_errors()
+
+    def get_current_errors(self):
+        import collections
+        names = ['app_gen_s', 'content_gen_s', 'style_gen_s', 'app_gen_t', 'ad_gen_t', 'dis_img_gen_t', 'content_gen_t',
+                 'style_gen_t']
+        return collections.OrderedDict((n, float(torch.as_tensor(getattr(self, 'loss_' + n)).detach())) for n in names)
+
+
+def synth_dptn_inputs(n, h=128, w=64, seed=0):
+    a = synth_dualgan_inputs(n, h, w, seed=seed)
+    b = synth_dualgan_inputs(n, h, w, seed=seed + 1000)
+    return {'Xs': a['Xs'], 'Ps': a['Ps'], 'Xt': b['Xs'], 'Pt': b['Ps']}

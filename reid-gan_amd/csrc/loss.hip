@@ -212,6 +212,26 @@ static unsigned grid_for(int64_t items) {
     return (unsigned)g;
 }
 
+
+// WGAN-GP penalty rows, CC/dual_gan/models/external_function.py:100-101: per sample r with g = grads[r] + 1e-16,
+// n = |g|_2: pen[r] = scale * (n - c)^2 and v[r] = d pen[r] / d grads[r] = scale * 2 (n - c) g / n.  One workgroup per row.
+__global__ __launch_bounds__(256) void grad_penalty_rows_kernel(const float* __restrict__ g, float* __restrict__ pen,
+                                                                float* __restrict__ v, int D, float c, float scale) {
+    __shared__ float red[16];
+    const float* gr = g + (int64_t)blockIdx.x * D;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float t = gr[i] + 1e-16f;
+        s += t * t;
+    }
+    s = rg_block_sum(s, red);
+    const float n = sqrtf(s);
+    if (threadIdx.x == 0) pen[blockIdx.x] = scale * (n - c) * (n - c);
+    const float k = n > 0.f ? scale * 2.f * (n - c) / n : 0.f;
+    float* vr = v + (int64_t)blockIdx.x * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) vr[i] = k * (gr[i] + 1e-16f);
+}
+
 }  // namespace
 
 extern "C" size_t rg_loss_workspace(void) { return kMaxPartials * sizeof(float); }
@@ -339,4 +359,12 @@ extern "C" int rg_weighted_sum_bwd(const float* grad_out, const float* w, float*
     RG_REQUIRE(dx && n > 0, "rg_weighted_sum_bwd: bad arguments");
     hipLaunchKernelGGL(wsum_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, grad_out, w, dx, n, scale);
     return rg::check_launch("rg_weighted_sum_bwd");
+}
+
+extern "C" int rg_grad_penalty_rows(const float* grads, float* pen, float* v, int rows, int D, float constant, float scale,
+                                    hipStream_t stream) {
+    RG_REQUIRE(grads && pen && v && rows > 0 && D > 0, "rg_grad_penalty_rows: bad arguments");
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 12.0 * rows * D);
+    hipLaunchKernelGGL(grad_penalty_rows_kernel, dim3(rows), dim3(256), 0, stream, grads, pen, v, D, constant, scale);
+    return rg::check_launch("rg_grad_penalty_rows");
 }

@@ -34,7 +34,8 @@ enum Family : int {
     FAM_CM = 7,
     FAM_OPTIM = 8,
     FAM_MISC = 9,
-    FAM_COUNT = 10
+    FAM_CONV_F8 = 10,
+    FAM_COUNT = 11
 };
 
 struct ProfScope {

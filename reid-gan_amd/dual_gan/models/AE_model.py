@@ -77,18 +77,26 @@ class AEModel(BaseModel):
         self.device = torch.device("cuda", torch.cuda.current_device())
 
         self.feat_bn = rnn.BatchNorm1d(num_feats).to(self.device)
-        if getattr(opt, 'bipath_gan', False) or getattr(opt, 'use_adp', False):
-            raise NotImplementedError("--bipath_gan / --use_adp: net_Gb / net_Db / net_A are built but never called by "
-                                      "the reference (SURVEY §9.6); not rebuilt")
-        self.net_G = networks.define_G(opt, image_nc=opt.image_nc, pose_nc=opt.pose_nc, ngf=64, img_f=num_feats,
-                                       encoder_layer=G_layer, norm=opt.norm, activation='LeakyReLU',
-                                       use_spect=opt.use_spect_g, use_coord=opt.use_coord, output_nc=3,
-                                       num_blocks=opt.num_blocks, affine=True, nhead=opt.nhead, num_CABs=opt.num_CABs,
-                                       num_TTBs=opt.num_TTBs)
-        self.use_adp = False
+        g_kw = dict(image_nc=opt.image_nc, pose_nc=opt.pose_nc, ngf=64, img_f=num_feats, encoder_layer=G_layer, norm=opt.norm,
+                    activation='LeakyReLU', use_spect=opt.use_spect_g, use_coord=opt.use_coord, output_nc=3, affine=True,
+                    nhead=opt.nhead, num_CABs=opt.num_CABs, num_TTBs=opt.num_TTBs)
+        self.net_G = networks.define_G(opt, num_blocks=opt.num_blocks, **g_kw)
+        # bipath (AE_model.py:78-88): a second generator that takes part in the optimizers and checkpoints; no method of the
+        # reference ever calls it, so it is constructed for API / state_dict parity and never run
+        self.bipath_gan = bool(getattr(opt, 'bipath_gan', False))
+        if self.bipath_gan:
+            self.model_names.append('Gb')
+            self.net_Gb = networks.define_G(opt, num_blocks=opt.num_CABs, **g_kw)
+        self.use_adp = bool(getattr(opt, 'use_adp', False))
+        if self.use_adp:
+            self.model_names.append('A')
+            self.net_A = networks.Resize_ReID(image_nc=opt.image_nc).to(self.device)
         if self.gan_train:
             self.model_names.append('D')
             self.net_D = networks.define_D(opt, ndf=32, img_f=128, layers=opt.dis_layers, use_spect=opt.use_spect_d)
+            if self.bipath_gan:
+                self.model_names.append('Db')
+                self.net_Db = networks.define_D(opt, ndf=32, img_f=128, layers=opt.dis_layers, use_spect=opt.use_spect_d)
 
         if getattr(self.opt, 'verbose', False):
             print('---------- Networks initialized -------------')
@@ -97,16 +105,22 @@ class AEModel(BaseModel):
             self.old_lr = opt.gan_lr
             self.GANloss = external_function.GANLoss(opt.gan_mode).to(self.device)
             if not opt.no_vgg_loss:
-                self.Vggloss = external_function.VGGLoss()
-            self.optimizer_G = roptim.Adam(itertools.chain(filter(lambda p: p.requires_grad, self.net_G.parameters())),
-                                           lr=opt.gan_lr, betas=(opt.beta1, 0.999))
+                self.Vggloss = external_function.VGGLoss(vgg_weights=getattr(opt, 'vgg_weights', '') or None).to(self.device)
+
+            def trainable(net):
+                return itertools.chain(filter(lambda p: p.requires_grad, net.parameters()))
+            if self.bipath_gan:            # two parameter groups per optimizer, as AE_model.py:130-156
+                g_groups = [{"params": trainable(self.net_G)}, {"params": trainable(self.net_Gb)}]
+                d_groups = [{"params": trainable(self.net_D)}, {"params": trainable(self.net_Db)}]
+            else:
+                g_groups, d_groups = trainable(self.net_G), trainable(self.net_D)
+            self.optimizer_G = roptim.Adam(g_groups, lr=opt.gan_lr, betas=(opt.beta1, 0.999))
             self.optimizers = [self.optimizer_G]
-            self.optimizer_D = roptim.Adam(itertools.chain(filter(lambda p: p.requires_grad, self.net_D.parameters())),
-                                           lr=opt.gan_lr * opt.ratio_g2d, betas=(opt.beta1, 0.999))
+            self.optimizer_D = roptim.Adam(d_groups, lr=opt.gan_lr * opt.ratio_g2d, betas=(opt.beta1, 0.999))
             self.optimizers.append(self.optimizer_D)
             self.schedulers = [base_function.get_scheduler(optimizer, opt) for optimizer in self.optimizers]
-            self._red_G = GradReducer(self.optimizer_G, modules=[self.net_G])
-            self._red_D = GradReducer(self.optimizer_D, modules=[self.net_D])
+            self._red_G = GradReducer(self.optimizer_G, modules=[self.net_G] + ([self.net_Gb] if self.bipath_gan else []))
+            self._red_D = GradReducer(self.optimizer_D, modules=[self.net_D] + ([self.net_Db] if self.bipath_gan else []))
             _wrap_step(self.optimizer_G, self._red_G)
             _wrap_step(self.optimizer_D, self._red_D)
         else:
@@ -174,9 +188,12 @@ class AEModel(BaseModel):
         D_real_loss = self.GANloss(D_real, True, True)
         D_fake = netD(fake.detach())
         D_fake_loss = self.GANloss(D_fake, False, True)
-        if self.opt.gan_mode == 'wgangp':
-            raise NotImplementedError("wgangp gradient penalty")
-        return _weighted([(D_real_loss, 0.5), (D_fake_loss, 0.5)])
+        terms = [(D_real_loss, 0.5), (D_fake_loss, 0.5)]
+        if self.opt.gan_mode == 'wgangp':                      # AE_model.py:304-306
+            gradient_penalty, _ = external_function.cal_gradient_penalty(netD, real, fake.detach(),
+                                                                         alpha=getattr(self, 'gp_alpha', None))
+            terms.append((gradient_penalty, 1.0))
+        return _weighted(terms)
 
     def backward_D(self):
         base_function._unfreeze(self.net_D)
@@ -194,10 +211,19 @@ class AEModel(BaseModel):
         if use_d:
             base_function._freeze(self.net_D)
             D_fake = self.net_D(fake_image)
-            loss_ad_gen = RF.mse_const(D_fake, self.GANloss.label(True))
-        if not self.opt.no_vgg_loss:
-            raise NotImplementedError("VGG perceptual loss (needs a network download); run with --no_vgg_loss")
-        return loss_app_gen, loss_ad_gen, None, None
+            if self.opt.gan_mode == 'lsgan':
+                loss_ad_gen = RF.mse_const(D_fake, self.GANloss.label(True))
+            else:
+                loss_ad_gen = self.GANloss(D_fake, True, False)
+        if self.opt.no_vgg_loss:
+            return loss_app_gen, loss_ad_gen, None, None
+        # the reference computes the perceptual terms here (:330-335) but none of its generator objectives adds them
+        # (:346, :371, :374): they are reported, detached values
+        with torch.no_grad():
+            loss_content_gen, loss_style_gen = self.Vggloss(fake_image.detach(), target_image)
+            loss_style_gen = loss_style_gen * self.opt.lambda_style
+            loss_content_gen = loss_content_gen * self.opt.lambda_content
+        return loss_app_gen, loss_ad_gen, loss_style_gen, loss_content_gen
 
     def _loss_G_mean(self):
         base_function._unfreeze(self.net_D)

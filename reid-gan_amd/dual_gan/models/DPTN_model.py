@@ -1,0 +1,235 @@
+"""DPTNModel — the dual-task pose transformer GAN object (BASELINE config 5) on the HIP runtime.
+
+Restates the training side of CC/dual_gan/models/DPTN_model.py:13-240: same constructor (`DPTNModel(opt)`), options
+(`modify_options` :18-42), attributes (net_G / net_D, optimizer_G / optimizer_D, loss_* names :48, visual names :50) and
+methods (set_input :117-133, forward :135-137, synthesize :139-144, synthesize_pair :146-155, backward_D_basic :159-174,
+backward_D :176-182, backward_G_basic :184-201, backward_G :203-214, optimize_parameters :216-225,
+optimize_parameters_generated :227-234).  `DPTNGenerator` runs its source->source and source->target branches as one
+stacked batch through the shared encoder / decoder (dual_gan/models/networks.py); `net_D` sees the target branch only.
+
+What differs from the reference is scheduling and three defects that are not reproduced:
+  * the generator update treats net_D as a constant (its weight gradients, which the reference computes and discards at
+    the next zero_grad, are not computed);
+  * `--gan_mode lsgan` makes `loss_ad_gen_t` a per-pixel map in the reference (external_function.py:53-57 returns the
+    un-reduced MSE for the generator form) and `G_loss.backward()` (:213) then raises "grad can be implicitly created
+    only for scalar outputs": this class raises the same RuntimeError at the same call, before touching any gradient;
+  * `VGGLoss()` downloads ImageNet weights in the reference's constructor (:77); here it is built only when the
+    perceptual terms are on (`--no_vgg_loss` absent) and takes `--vgg_weights <local torchvision vgg19 state_dict>`;
+    with `--no_vgg_loss` the content / style losses are reported as 0, as the run configuration of BASELINE config 5;
+  * test-time image dumping (`test`, `save_results`), the `net_A` adaptor (`--use_adp`, needs torchvision's resize module
+    graph) are outside the training step and not rebuilt.
+
+`--conv_dtype fp8` switches every convolution of net_G and net_D to the fp8 MFMA family (csrc/conv_f8.hip: e4m3
+activations and filters, e5m2 gradients, per-tensor scales, fp32 accumulation); the default is the fp32 family.
+"""
+from __future__ import absolute_import
+
+import itertools
+import os
+
+import torch
+
+from rg_hip import functional as RF
+from rg_hip import optim as roptim
+from rg_hip.parallel import GradReducer
+from rg_hip.tape import no_param_grad
+
+from . import base_function, external_function, networks
+from .AE_model import _weighted, _wrap_step
+from .base_model import BaseModel
+
+
+class DPTNModel(BaseModel):
+    def name(self):
+        return 'DPTNModel'
+
+    @staticmethod
+    def modify_options(parser, is_train=True):
+        """Add new options and rewrite default values for existing options (DPTN_model.py:18-42)"""
+        parser.add_argument('--init_type', type=str, default='orthogonal', help='initial type')
+        parser.add_argument('--use_spect_g', action='store_false', help='use spectual normalization in generator')
+        parser.add_argument('--use_spect_d', action='store_false', help='use spectual normalization in generator')
+        parser.add_argument('--use_coord', action='store_true', help='use coordconv')
+        parser.add_argument('--lambda_style', type=float, default=500, help='weight for the VGG19 style loss')
+        parser.add_argument('--lambda_content', type=float, default=0.5, help='weight for the VGG19 content loss')
+        parser.add_argument('--layers_g', type=int, default=3, help='number of layers in G')
+        parser.add_argument('--save_input', action='store_true', help="whether save the input images when testing")
+        parser.add_argument('--num_blocks', type=int, default=3, help="number of resblocks")
+        parser.add_argument('--affine', action='store_true', default=True, help="affine in PTM")
+        parser.add_argument('--nhead', type=int, default=2, help="number of heads in PTM")
+        parser.add_argument('--num_CABs', type=int, default=2, help="number of CABs in PTM")
+        parser.add_argument('--num_TTBs', type=int, default=2, help="number of CABs in PTM")
+        parser.add_argument('--ratio_g2d', type=float, default=0.1, help='learning rate ratio G to D')
+        parser.add_argument('--lambda_rec', type=float, default=2.0, help='weight for image reconstruction loss')
+        parser.add_argument('--lambda_g', type=float, default=5.0, help='weight for generation loss')
+        parser.add_argument('--t_s_ratio', type=float, default=0.8, help='loss ratio between dual tasks')
+        parser.add_argument('--dis_layers', type=int, default=3, help='number of layers in D')
+        parser.add_argument('--vgg_weights', type=str, default='', help='local torchvision vgg19 state_dict (.pth)')
+        parser.add_argument('--conv_dtype', type=str, default='fp32', help='fp32 | fp8: MFMA family of the convolutions')
+        parser.add_argument('--f8_scaling', type=str, default='delayed', help='delayed | jit: per-tensor fp8 scale policy')
+        parser.set_defaults(use_spect_g=False)
+        parser.set_defaults(use_spect_d=True)
+        return parser
+
+    def __init__(self, opt):
+        BaseModel.__init__(self, opt)
+        self.old_size = getattr(opt, 'old_size', None)
+        self.t_s_ratio = opt.t_s_ratio
+        self.loss_names = ['app_gen_s', 'content_gen_s', 'style_gen_s', 'app_gen_t', 'ad_gen_t', 'dis_img_gen_t', 'content_gen_t',
+                           'style_gen_t']
+        self.model_names = ['G']
+        self.visual_names = ['source_image', 'source_pose', 'target_image', 'target_pose', 'fake_image_s', 'fake_image_t']
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+        self.net_G = networks.define_G(opt, image_nc=opt.image_nc, pose_nc=opt.pose_nc, ngf=64, img_f=512, encoder_layer=3,
+                                       norm=opt.norm, activation='LeakyReLU', use_spect=opt.use_spect_g,
+                                       use_coord=opt.use_coord, output_nc=3, num_blocks=3, affine=True, nhead=opt.nhead,
+                                       num_CABs=opt.num_CABs, num_TTBs=opt.num_TTBs)
+        self.use_adp = getattr(opt, 'use_adp', False)
+        if self.use_adp:
+            raise NotImplementedError("--use_adp: net_A (Resize_ReID) is not on the training step and not rebuilt")
+
+        if self.gan_train:
+            self.model_names = ['G', 'D']
+            self.net_D = networks.define_D(opt, ndf=32, img_f=128, layers=opt.dis_layers, use_spect=opt.use_spect_d)
+        self.conv_dtype = getattr(opt, 'conv_dtype', 'fp32')
+        if self.conv_dtype not in ('fp32', 'fp8'):
+            raise ValueError("--conv_dtype %r: expected fp32 or fp8" % (self.conv_dtype,))
+        self._f8_states = []
+        if self.conv_dtype == 'fp8':
+            from rg_hip import lowp
+            policy = getattr(opt, 'f8_scaling', 'delayed')
+            self._f8_states.append(lowp.set_conv_dtype(self.net_G, 'fp8', policy=policy))
+            if self.gan_train:
+                self._f8_states.append(lowp.set_conv_dtype(self.net_D, 'fp8', policy=policy))
+
+        if getattr(self.opt, 'verbose', False):
+            print('---------- Networks initialized -------------')
+        if self.gan_train:
+            self.old_lr = opt.gan_lr
+            self.GANloss = external_function.GANLoss(opt.gan_mode).to(self.device)
+            self.no_vgg = bool(getattr(opt, 'no_vgg_loss', False))
+            if not self.no_vgg:
+                self.Vggloss = external_function.VGGLoss(vgg_weights=getattr(opt, 'vgg_weights', '') or None).to(self.device)
+            self.optimizer_G = roptim.Adam(itertools.chain(filter(lambda p: p.requires_grad, self.net_G.parameters())),
+                                           lr=opt.gan_lr, betas=(opt.beta1, 0.999))
+            self.optimizers = [self.optimizer_G]
+            self.optimizer_D = roptim.Adam(itertools.chain(filter(lambda p: p.requires_grad, self.net_D.parameters())),
+                                           lr=opt.gan_lr * opt.ratio_g2d, betas=(opt.beta1, 0.999))
+            self.optimizers.append(self.optimizer_D)
+            self.schedulers = [base_function.get_scheduler(optimizer, opt) for optimizer in self.optimizers]
+            self._red_G = GradReducer(self.optimizer_G, modules=[self.net_G])
+            self._red_D = GradReducer(self.optimizer_D, modules=[self.net_D])
+            _wrap_step(self.optimizer_G, self._red_G)
+            _wrap_step(self.optimizer_D, self._red_D)
+        else:
+            self.net_G.eval()
+
+        if self.load_pretrain != "" or getattr(opt, 'continue_train', False):
+            print('model loaded from pretrained')
+            self.load_networks(opt.which_epoch)
+
+    # ---- inputs / synthesis (DPTN_model.py:117-155) ---------------------------------------------------------
+    def set_input(self, input, b_id=None):
+        self.input = input
+        if b_id is not None:
+            source_image, source_pose = torch.index_select(input['Xs'], 0, b_id), torch.index_select(input['Ps'], 0, b_id)
+            target_image, target_pose = torch.index_select(input['Xt'], 0, b_id), torch.index_select(input['Pt'], 0, b_id)
+        else:
+            source_image, source_pose = input['Xs'], input['Ps']
+            target_image, target_pose = input['Xt'], input['Pt']
+        dev = self.device
+        self.source_image = source_image.to(dev, non_blocking=True).contiguous()
+        self.source_pose = source_pose.to(dev, non_blocking=True).contiguous()
+        self.target_image = target_image.to(dev, non_blocking=True).contiguous()
+        self.target_pose = target_pose.to(dev, non_blocking=True).contiguous()
+        self.image_paths = []
+        if 'Xs_path' in input and 'Xt_path' in input:
+            for i in range(self.source_image.size(0)):
+                self.image_paths.append(os.path.splitext(input['Xs_path'][i])[0] + '_2_' + input['Xt_path'][i])
+
+    def forward(self):
+        self.fake_image_t, self.fake_image_s = self.net_G(self.source_image, self.source_pose, self.target_pose)
+
+    def synthesize(self, is_tain=False):
+        self.fake_image_t, self.fake_image_s = self.net_G(self.source_image, self.source_pose, self.target_pose, is_tain)
+        return self.fake_image_t, self.fake_image_s
+
+    def synthesize_pair(self):
+        self.fake_image_n, _ = self.net_G(torch.flip(self.source_image, dims=[0]).contiguous(),
+                                          torch.flip(self.source_pose, dims=[0]).contiguous(), self.target_pose, False)
+        return self.fake_image_n
+
+    # ---- discriminator update (DPTN_model.py:159-182) --------------------------------------------------------
+    def backward_D_basic(self, netD, real, fake):
+        D_real = netD(real)
+        D_real_loss = self.GANloss(D_real, True, True)
+        D_fake = netD(fake.detach())
+        D_fake_loss = self.GANloss(D_fake, False, True)
+        terms = [(D_real_loss, 0.5), (D_fake_loss, 0.5)]
+        if self.opt.gan_mode == 'wgangp':
+            gradient_penalty, _ = external_function.cal_gradient_penalty(netD, real, fake.detach(),
+                                                                         alpha=getattr(self, 'gp_alpha', None))
+            terms.append((gradient_penalty, 1.0))
+        return _weighted(terms)
+
+    def backward_D(self):
+        base_function._unfreeze(self.net_D)
+        self.loss_dis_img_gen_t = self.backward_D_basic(self.net_D, self.target_image, self.fake_image_t)
+        D_loss = self.loss_dis_img_gen_t
+        D_loss.backward()
+        self.loss_dis_img_gen_t = D_loss.detach()
+
+    # ---- generator update (DPTN_model.py:184-214) ----------------------------------------------------------------
+    def backward_G_basic(self, fake_image, target_image, use_d):
+        """(lambda_rec * L1, lambda_g * GAN loss or None, lambda_style * style, lambda_content * content), all attached 0-dim
+        device tensors; with the perceptual terms off the last two are detached zeros."""
+        loss_app_gen = _weighted([(RF.l1_loss(fake_image, target_image), self.opt.lambda_rec)])
+        loss_ad_gen = None
+        if use_d:
+            with no_param_grad(self.net_D.module if hasattr(self.net_D, "module") else self.net_D):
+                D_fake = self.net_D(fake_image)
+            loss_ad_gen = self.GANloss(D_fake, True, False)
+            if loss_ad_gen.dim() == 0:
+                loss_ad_gen = _weighted([(loss_ad_gen, self.opt.lambda_g)])
+        if self.no_vgg:
+            zero = torch.zeros((), device=fake_image.device)
+            return loss_app_gen, loss_ad_gen, zero, zero
+        loss_content_gen, loss_style_gen = self.Vggloss(fake_image, target_image)
+        loss_style_gen = _weighted([(loss_style_gen, self.opt.lambda_style)])
+        loss_content_gen = _weighted([(loss_content_gen, self.opt.lambda_content)])
+        return loss_app_gen, loss_ad_gen, loss_style_gen, loss_content_gen
+
+    def backward_G(self, retain_graph=False):
+        base_function._unfreeze(self.net_D)
+        self.loss_app_gen_t, self.loss_ad_gen_t, self.loss_style_gen_t, self.loss_content_gen_t = \
+            self.backward_G_basic(self.fake_image_t, self.target_image, use_d=True)
+        self.loss_app_gen_s, self.loss_ad_gen_s, self.loss_style_gen_s, self.loss_content_gen_s = \
+            self.backward_G_basic(self.fake_image_s, self.source_image, use_d=False)
+        if self.loss_ad_gen_t.dim() != 0:
+            # lsgan: the un-reduced generator form makes G_loss a map; the reference's G_loss.backward() (:213) raises this
+            raise RuntimeError("grad can be implicitly created only for scalar outputs")
+        r = self.t_s_ratio
+        terms = [(self.loss_app_gen_t, r), (self.loss_app_gen_s, 1 - r), (self.loss_ad_gen_t, 1.0)]
+        if not self.no_vgg:
+            terms += [(self.loss_style_gen_t, r), (self.loss_content_gen_t, r), (self.loss_style_gen_s, 1 - r),
+                      (self.loss_content_gen_s, 1 - r)]
+        G_loss = _weighted(terms)
+        G_loss.backward(retain_graph=retain_graph)
+        for n in ('app_gen_t', 'ad_gen_t', 'style_gen_t', 'content_gen_t', 'app_gen_s', 'style_gen_s', 'content_gen_s'):
+            setattr(self, 'loss_' + n, getattr(self, 'loss_' + n).detach())
+
+    def optimize_parameters(self):
+        self.forward()
+        self.optimize_parameters_generated()
+
+    def optimize_parameters_generated(self):
+        self.optimizer_D.zero_grad()
+        self.backward_D()
+        self.optimizer_D.step()
+
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        self.optimizer_G.step()
+        for st in self._f8_states:          # delayed fp8 scaling: the maxima collected during this step become current
+            st.roll()

@@ -193,6 +193,41 @@ class SourceEncoder(RGModule):
         return dy
 
 
+class Resize_ReID(RGModule):
+    """Adaptor from synthesised 128x64 images to ReID inputs (networks.py:140-162): bicubic resize to 256x128
+    (`my_resize`, rg_bicubic_normalize without the normalisation) followed by three residual blocks added back onto the
+    resized image.  Built by `--use_adp`; no method of the reference's training loops calls it."""
+
+    def __init__(self, image_nc, ngf=64, norm='batch', activation='ReLU', use_spect=True, use_coord=False):
+        super(Resize_ReID, self).__init__()
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        self.resblock1 = ResBlock(image_nc, ngf, norm_layer=norm_layer, nonlinearity=nonlinearity, sample_type='none',
+                                  use_spect=use_spect, use_coord=use_coord)
+        self.resblock2 = ResBlock(ngf, ngf, norm_layer=norm_layer, nonlinearity=nonlinearity, sample_type='none',
+                                  use_spect=use_spect, use_coord=use_coord)
+        self.resblock3 = ResBlock(ngf, image_nc, norm_layer=norm_layer, nonlinearity=nonlinearity, sample_type='none',
+                                  use_spect=use_spect, use_coord=use_coord)
+
+    def tf(self, tape, inputs):
+        x = ops.bicubic_normalize_fwd(inputs, (256, 128))
+        tape.push(tuple(inputs.shape[2:]))
+        out = self.resblock1.tf(tape, x)
+        out = self.resblock2.tf(tape, out)
+        out = self.resblock3.tf(tape, out)
+        return ops.add(x, out)
+
+    def tb(self, tape, dy, need_dx=True):
+        dy = dy.contiguous()
+        d = self.resblock3.tb(tape, dy)
+        d = self.resblock2.tb(tape, d)
+        d = self.resblock1.tb(tape, d, need_dx=need_dx)
+        hw = tape.pop()
+        if not need_dx:
+            return None
+        return ops.bicubic_normalize_bwd(ops.add(d, dy), hw)
+
+
 class DPTNGenerator(RGModule):
     """Dual-task Pose Transformer Network generator (networks.py:165-275): a source->source and a source->target branch
     through SHARED encoder / decoder weights, coupled by the PTM.  Both branches run as ONE 2B batch through the shared
@@ -413,3 +448,92 @@ class ResDiscriminator(RGModule):
             d = getattr(self, 'encoder' + str(i)).tb(tape, d)
         need = tape.needs_input is None or bool(tape.needs_input[0])
         return self.block0.tb(tape, d, need_dx=need)
+
+    # ---- WGAN-GP: input gradient, tangent pass and second-order weight gradients (external_function.cal_gradient_penalty) ----
+    def _gp_blocks(self):
+        if any(isinstance(m, (rnn.BatchNorm2d, rnn.InstanceNorm2d)) for m in self.modules()):
+            raise NotImplementedError("gradient penalty: built for the norm='none' discriminator define_D constructs")
+        blocks = [(None, self.block0.model[0], self.block0.model[2], self.block0.shortcut[1])]
+        for i in range(self.layers - 1):
+            b = getattr(self, 'encoder' + str(i))
+            blocks.append((True, b.model[1], b.model[3], b.shortcut[1]))
+        return blocks
+
+    @staticmethod
+    def _gp_weight(conv, training):
+        """effective filter of one convolution for this forward: (w, w_krsc, spectral-norm record or None)"""
+        if isinstance(conv, rnn.SNConv2d):
+            w_sn, sigma = ops.spectral_norm_fwd(conv.weight_orig.detach(), conv.weight_u, conv.weight_v, training, conv.eps)
+            conv.weight = w_sn
+            rec = (sigma, conv.weight_u.clone(), conv.weight_v.clone())
+            w = w_sn
+        else:
+            w, rec = conv.weight.detach(), None
+        wk = ops.weights_to_krsc(w) if (w.shape[2] * w.shape[3] > 1 and w.shape[1] % 4 == 0) else None
+        return w, wk, rec
+
+    def gp_forward(self, tape, x):
+        """D(x) (one more power iteration in training mode, as every reference forward), then the adjoint pass with ones at
+        the output: returns g = d sum(D(x)) / dx and, for the second-order step, every convolution's effective filter,
+        LeakyReLU output and output adjoint."""
+        act, slope = _slope(self.nonlinearity)
+        recs, h = [], x
+        for pre_act, c1, c2, cb in self._gp_blocks():
+            W1, W2, Wb = (self._gp_weight(c, self.training) for c in (c1, c2, cb))
+            a = ops.act_fwd(h, act, slope) if pre_act else None
+            h1 = ops.conv2d_fwd(a if pre_act else h, W1[0], c1.stride, c1.padding, shift=c1.bias, act=act, slope=slope, w_krsc=W1[1])
+            m = ops.conv2d_fwd(h1, W2[0], c2.stride, c2.padding, shift=c2.bias, w_krsc=W2[1])
+            out = ops.conv2d_fwd(ops.avgpool2d_fwd(h, 2), Wb[0], cb.stride, cb.padding, shift=cb.bias, residual=m, w_krsc=Wb[1])
+            recs.append(dict(c1=c1, c2=c2, cb=cb, W1=W1, W2=W2, Wb=Wb, a=a, h1=h1, x_shape=h.shape))
+            h = out
+        Wc = self._gp_weight(self.conv, self.training)
+        a_f = ops.act_fwd(h, act, slope)
+        y = ops.conv2d_fwd(a_f, Wc[0], self.conv.stride, self.conv.padding, shift=self.conv.bias, w_krsc=Wc[1])
+        # adjoint pass
+        ones = ops.fill_(torch.empty_like(y), 1.0)
+        d = ops.act_bwd(ops.conv2d_dgrad(ones, Wc[0], a_f.shape[2:], self.conv.stride, self.conv.padding, w_krsc=Wc[1]), a_f, act, slope)
+        for r in reversed(recs):
+            c1, c2, cb = r['c1'], r['c2'], r['cb']
+            r['d_out'] = d
+            hw = r['x_shape'][2:]
+            dxs = ops.avgpool2d_bwd(ops.conv2d_dgrad(d, r['Wb'][0], (hw[0] // 2, hw[1] // 2), cb.stride, cb.padding, w_krsc=r['Wb'][1]),
+                                    tuple(r['x_shape']), 2)
+            d1 = ops.act_bwd(ops.conv2d_dgrad(d, r['W2'][0], r['h1'].shape[2:], c2.stride, c2.padding, w_krsc=r['W2'][1]),
+                             r['h1'], act, slope)
+            r['d_1'] = d1
+            din = ops.conv2d_dgrad(d1, r['W1'][0], hw, c1.stride, c1.padding, w_krsc=r['W1'][1])
+            if r['a'] is not None:
+                din = ops.act_bwd(din, r['a'], act, slope)
+            d = ops.axpby(din, dxs, 1.0, 1.0, out=din)
+        return d, dict(recs=recs, Wc=Wc, a_f=a_f, ones=ones)
+
+    def gp_backward(self, tape, adj, v, g_pen):
+        """{id(param): gradient} of g_pen * <v, g(W)>: tangent pass of v through the masked-linear network, then
+        wgrad(input tangent, output adjoint) per convolution, mapped through W / sigma for spectral-normed filters."""
+        act, slope = _slope(self.nonlinearity)
+        t = ops.weighted_sum_bwd(g_pen, v.reshape(-1).contiguous(), v.numel(), 1.0, v.device).view(v.shape)
+        grads = {}
+
+        def wgrad(conv, W, t_in, d_out):
+            dw = ops.conv2d_wgrad(t_in.contiguous(), d_out.contiguous(), W[0].shape, conv.stride, conv.padding)
+            if W[2] is not None:
+                sigma, u, vv = W[2]
+                p = conv.weight_orig
+                dw = ops.spectral_norm_bwd(dw, W[0], u, vv, sigma)
+            else:
+                p = conv.weight
+            if p.requires_grad:
+                grads[id(p)] = dw
+
+        for r in adj['recs']:
+            c1, c2, cb = r['c1'], r['c2'], r['cb']
+            ta = ops.act_bwd(t, r['a'], act, slope) if r['a'] is not None else t
+            wgrad(c1, r['W1'], ta, r['d_1'])
+            t1 = ops.act_bwd(ops.conv2d_fwd(ta, r['W1'][0], c1.stride, c1.padding, w_krsc=r['W1'][1]), r['h1'], act, slope)
+            wgrad(c2, r['W2'], t1, r['d_out'])
+            tm = ops.conv2d_fwd(t1, r['W2'][0], c2.stride, c2.padding, w_krsc=r['W2'][1])
+            tp = ops.avgpool2d_fwd(t, 2)
+            wgrad(cb, r['Wb'], tp, r['d_out'])
+            t = ops.conv2d_fwd(tp, r['Wb'][0], cb.stride, cb.padding, residual=tm, w_krsc=r['Wb'][1])
+        wgrad(self.conv, adj['Wc'], ops.act_bwd(t, adj['a_f'], act, slope), adj['ones'])
+        return grads

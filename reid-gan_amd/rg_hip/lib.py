@@ -122,4 +122,4 @@ class _Lib(object):
 
 lib = _Lib()
 
-FAMILIES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "norm", "eltwise", "pool", "loss", "cm", "optim", "misc"]
+FAMILIES = ["conv_fwd", "conv_dgrad", "conv_wgrad", "norm", "eltwise", "pool", "loss", "cm", "optim", "misc", "conv_f8"]

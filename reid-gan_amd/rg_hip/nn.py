@@ -60,8 +60,28 @@ class Conv2d(RGModule, _KrscCache):
         return "%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s" % (
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
 
+    def _geom(self, x):
+        return (x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.weight.shape[0], self.kernel_size[0], self.kernel_size[1],
+                self.stride[0], self.stride[1], self.padding[0], self.padding[1])
+
+    def _wkey(self):
+        w = self.weight
+        arena = getattr(w, "_rg_arena", None)
+        return (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
+
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         """y = act(conv(x) + bias + residual): bias, residual add and activation run in the MFMA epilogue."""
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            # fp8 MFMA family (rg_hip.lowp): e4m3 operands, fp32 accumulate, same fused epilogue
+            from . import lowp
+            want_w = tape.record and tape.wants(self.weight)
+            xq, xq_t = f8.quant_act_both(x, want_w)
+            wq, _ = f8.weights(self.weight.detach(), self._wkey())
+            geom = self._geom(x)
+            y = lowp.conv_fwd(xq, wq, geom, shift=self.bias, residual=residual, act=act, slope=slope)
+            tape.push((xq_t, y if act != ACT_NONE else None, act, slope, geom))
+            return y
         if self._full_extent(x):
             # the filter covers the whole (unpadded) map — the generator's 512 -> 128 (8,4) bottleneck,
             # FD/fdgan/networks.py:96-100: a plain GEMM x[N][C*H*W] . w[K][C*KH*KW]^T, run with 1x1 geometry
@@ -82,6 +102,24 @@ class Conv2d(RGModule, _KrscCache):
         """mask_input: the conv's input x is the ReLU output of the layer below — its backward (zero where x <= 0) is
         applied to dx (+ residual) in the dgrad epilogue.  dx_channels=(c0, c1): only that channel range of the input
         receives a gradient (the rest of a concatenated input is constant) -> dx has c1 - c0 channels."""
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            from . import lowp
+            if mask_input or dx_channels is not None or want_rowsum:
+                raise NotImplementedError("Conv2d(fp8): mask_input / dx_channels / want_rowsum belong to the fp32 ResNet programs")
+            xq_t, y, act, slope, geom = tape.pop()
+            if act != ACT_NONE:
+                dy = ops.act_bwd(dy, y, act, slope)
+            want_w = tape.wants(self.weight)
+            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            if want_w:
+                tape.add_grad(self.weight, lowp.conv_wgrad(xq_t, dyq_t, geom, out=tape.grad_out(self.weight)))
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            if not need_dx:
+                return None
+            _, wq_t = f8.weights(self.weight.detach(), self._wkey())
+            return lowp.conv_dgrad(dyq, wq_t, geom, (geom[2], geom[3]), residual=residual)
         x, y, act, slope = tape.pop()
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
@@ -125,8 +163,30 @@ class ConvTranspose2d(RGModule, _KrscCache):
         return ((H - 1) * self.stride[0] - 2 * self.padding[0] + self.kernel_size[0] + self.output_padding[0],
                 (W - 1) * self.stride[1] - 2 * self.padding[1] + self.kernel_size[1] + self.output_padding[1])
 
+    def _geom(self, hw):
+        """geometry of the convolution whose data gradient is this layer's forward: (N filled by the caller, C = out_channels,
+        H, W = output size, K = in_channels, ...)"""
+        return (self.out_channels, hw[0], hw[1], self.in_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                self.stride[1], self.padding[0], self.padding[1])
+
+    def _wkey(self):
+        w = self.weight
+        arena = getattr(w, "_rg_arena", None)
+        return (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
+
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         hw = self.out_hw(x.shape[2], x.shape[3])
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            # forward == data gradient of the convolution with this weight tensor: x plays dy (e4m3 here), filters [C][RS][Kp]
+            from . import lowp
+            want_w = tape.record and tape.wants(self.weight)
+            xq, xq_t = f8.quant_act_both(x, want_w)
+            _, wq_t = f8.weights(self.weight.detach(), self._wkey())
+            geom = (x.shape[0],) + self._geom(hw)
+            y = lowp.conv_dgrad(xq, wq_t, geom, hw, shift=self.bias, residual=residual, act=act, slope=slope)
+            tape.push((xq_t, y if act != ACT_NONE else None, act, slope, geom))
+            return y
         if (x.shape[2] == 1 and x.shape[3] == 1 and self.padding == (0, 0) and self.output_padding == (0, 0)
                 and self.bias is None and act == ACT_NONE and residual is None):
             # a 1x1 input makes the transposed conv a plain GEMM x[N][K] . w[K][C*KH*KW] (the generator's
@@ -142,6 +202,23 @@ class ConvTranspose2d(RGModule, _KrscCache):
         return y
 
     def tb(self, tape, dy, need_dx=True, residual=None):
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            from . import lowp
+            xq_t, y, act, slope, geom = tape.pop()
+            if act != ACT_NONE:
+                dy = ops.act_bwd(dy, y, act, slope)
+            want_w = tape.wants(self.weight)
+            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            if want_w:
+                # filter gradient with the roles swapped: the "input" is dy (e5m2), the "output gradient" is x (e4m3)
+                tape.add_grad(self.weight, lowp.conv_wgrad(dyq_t, xq_t, geom, out=tape.grad_out(self.weight)))
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            if not need_dx:
+                return None
+            wq, _ = f8.weights(self.weight.detach(), self._wkey())
+            return lowp.conv_fwd(dyq, wq, geom, residual=residual)
         x, y, act, slope = tape.pop()
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
@@ -702,6 +779,18 @@ class SNConv2d(RGModule):
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         w_sn, sigma = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training, self.eps)
         self.weight = w_sn
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            from . import lowp
+            keep_uv = tape.record and tape.wants(self.weight_orig)
+            xq, xq_t = f8.quant_act_both(x, keep_uv)
+            wq, wq_t = f8.weights(w_sn, None)                      # W / sigma changes with every power iteration
+            geom = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], w_sn.shape[0], self.kernel_size[0], self.kernel_size[1],
+                    self.stride[0], self.stride[1], self.padding[0], self.padding[1])
+            y = lowp.conv_fwd(xq, wq, geom, shift=self.bias, residual=residual, act=act, slope=slope)
+            tape.push((xq_t, y if act != ACT_NONE else None, act, slope, w_sn, (wq_t, geom), sigma,
+                       self.weight_u.clone() if keep_uv else None, self.weight_v.clone() if keep_uv else None))
+            return y
         wk = ops.weights_to_krsc(w_sn) if (w_sn.shape[2] * w_sn.shape[3] > 1 and w_sn.shape[1] % 4 == 0) else None
         y = ops.conv2d_fwd(x, w_sn, self.stride, self.padding, shift=self.bias, residual=residual, act=act, slope=slope,
                            w_krsc=wk)
@@ -714,6 +803,21 @@ class SNConv2d(RGModule):
         x, y, act, slope, w_sn, wk, sigma, u, v = tape.pop()
         if act != ACT_NONE:
             dy = ops.act_bwd(dy, y, act, slope)
+        f8 = self.__dict__.get("_rg_f8")
+        if f8 is not None:
+            from . import lowp
+            wq_t, geom = wk
+            want_w = tape.wants(self.weight_orig)
+            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            if want_w:
+                dw_sn = lowp.conv_wgrad(x, dyq_t, geom)
+                tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,
+                                                                      out=tape.grad_out(self.weight_orig)))
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            if not need_dx:
+                return None
+            return lowp.conv_dgrad(dyq, wq_t, geom, (geom[2], geom[3]), residual=residual)
         if tape.wants(self.weight_orig):
             dw_sn = ops.conv2d_wgrad(x, dy, w_sn.shape, self.stride, self.padding)
             tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,

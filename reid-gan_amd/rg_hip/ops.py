@@ -747,6 +747,16 @@ def affine_relu_mean_bwd(x, grad_out, a, b, clamp, grad_scale=1.0):
     return dx
 
 
+def grad_penalty_rows(g, constant, scale):
+    """(pen[rows], v[rows, D]): pen[r] = scale * (|g_r + 1e-16| - constant)^2 and its gradient with respect to g_r."""
+    g = _chk(g, "g")
+    rows, D = g.shape
+    pen = torch.empty(rows, dtype=torch.float32, device=g.device)
+    v = torch.empty_like(g)
+    lib.rg_grad_penalty_rows(_p(g), _p(pen), _p(v), rows, D, float(constant), float(scale), _stream())
+    return pen, v
+
+
 def l1_fwd(a, b, row_labels=None):
     a, b = _chk(a, "a"), _chk(b, "b")
     row_labels = _chk(row_labels, "row_labels", torch.int64)

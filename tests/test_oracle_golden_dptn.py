@@ -1,0 +1,100 @@
+"""CPU: the DPTNModel oracle (oracle/ref_dualgan.py: GANLoss modes, gradient penalty, VGG19 / VGGLoss, the step driver)
+against the golden vectors recorded from the reference's own DPTNModel by tests/golden/make_golden_dptn.py.  No reference and
+no GPU needed; also the fp8 emulation's self-consistency (oracle/ref_fp8.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_dualgan as D
+from oracle import ref_fp8 as R
+from tests.golden import cases_dptn as C
+from tests.golden.cases import sub
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_dptn.npz"))
+
+
+def _cmp(got, key, tol=2e-5):
+    ref = GOLD[key]
+    got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+    scale = max(np.abs(ref).max(), 1e-12)
+    assert np.abs(got - ref).max() <= tol * scale, "%s: %.3e vs scale %.3e" % (key, np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("mode", C.GAN_MODES)
+def test_ganloss_modes(mode):
+    pred = C.ganloss_case()
+    vals = [D.o_ganloss(pred, real, is_disc, mode).mean().item() for real in (True, False) for is_disc in (True, False)]
+    _cmp(vals, "ganloss_" + mode)
+
+
+def test_vgg_loss():
+    x, y = C.vgg_pair()
+    vgg = D.OVGGLoss(D.OVGG19(C.vgg_features()))
+    x = x.clone().requires_grad_(True)
+    content, style = vgg(x, y)
+    (content + 500.0 * style).backward()
+    _cmp([content.item(), style.item()], "vgg_losses")
+    _cmp(sub(x.grad)[0], "vgg_dx", 1e-4)
+    feats = vgg.vgg(x.detach())
+    _cmp([feats[k].mean().item() for k, _, _ in D._VGG_SLICES], "vgg_relu_means")
+
+
+def test_gradient_penalty():
+    _, net_D = C.nets()
+    d = C.inputs()
+    alpha = torch.from_numpy(GOLD["gp_alpha"]).float()
+    gp, _ = D.o_cal_gradient_penalty(net_D, d['Xt'], d['Xs'], alpha)
+    gp.backward()
+    _cmp([gp.item()], "gp_value")
+    params = dict(net_D.named_parameters())
+    for k in C.PROBES_D:
+        _cmp(sub(params[k].grad)[0], "gp_g_" + k, 2e-4)
+
+
+@pytest.mark.parametrize("mode,with_vgg", [("hinge", False), ("hinge", True), ("vanilla", False), ("wgangp", False)])
+def test_dptn_step(mode, with_vgg):
+    tag = mode + ("_vgg" if with_vgg else "")
+    m = C.model(mode, with_vgg)
+    d = C.inputs()
+    for step in range(2):
+        if mode == "wgangp":
+            m.gp_alpha = C.gp_alpha(step)
+        errs = m.step(d)
+        _cmp([errs[k] for k in errs], "dptn_%s_losses_%d" % (tag, step), 1e-4)
+        _cmp(sub(m.fake_image_t.detach())[0], "dptn_%s_fake_t_%d" % (tag, step), 1e-4)
+        _cmp(sub(m.fake_image_s.detach())[0], "dptn_%s_fake_s_%d" % (tag, step), 1e-4)
+    pg = dict(m.net_G.named_parameters())
+    for k in C.PROBES_G:
+        _cmp(sub(pg[k].detach())[0], "dptn_%s_p_%s" % (tag, k), 1e-4)
+    pd = dict(m.net_D.named_parameters())
+    for k in C.PROBES_D:
+        _cmp(sub(pd[k].detach())[0], "dptn_%s_pd_%s" % (tag, k), 1e-4)
+
+
+def test_lsgan_fails_like_the_reference():
+    m = C.model("lsgan", False)
+    with pytest.raises(RuntimeError, match="scalar outputs"):
+        m.step(C.inputs())
+    assert "scalar outputs" in bytes(GOLD["lsgan_error"].astype(np.uint8)).decode()
+
+
+def test_fp8_emulation_properties():
+    """the fp8 specification itself: byte layouts are permutations with zero padding, quantisation is idempotent, scaling
+    round-trips the maximum exactly, and the emulated GEMMs are linear in their operands' scales"""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 4, 2, generator=g) * 7
+    for fmt in (0, 1):
+        xq, d = R.quantize(x, x.abs().max(), fmt)
+        assert float(xq.float().abs().max()) == R.FMAX[fmt]                    # the maximum maps onto the format maximum
+        xq2, _ = R.quantize(xq.float() * d, x.abs().max(), fmt)
+        assert torch.equal(xq.view(torch.uint8), xq2.view(torch.uint8))          # idempotent
+        a, b = R.to_layout(xq, "nhwc"), R.to_layout(xq, "chwn")
+        assert a.shape == (3, 8, 16) and b.shape == (5, 8, 16)
+        assert int(a[:, :, 5:].sum()) == 0 and int(b[:, :, 3:].sum()) == 0       # zero padding
+        assert torch.equal(a[:, :, :5].permute(0, 2, 1).reshape(3, 5, 8), xq.view(torch.uint8).reshape(3, 5, 8))
+    w = torch.randn(6, 5, 3, 3, generator=g)
+    y1 = R.conv_fwd(x, w, padding=1)
+    y2 = R.conv_fwd(x * 4.0, w * 0.5, padding=1)                                  # power-of-two rescaling is exact in fp8
+    assert torch.allclose(y2, y1 * 2.0, rtol=1e-6, atol=0)
