@@ -99,9 +99,13 @@ class DPTNModel(BaseModel):
         if self.conv_dtype == 'fp8':
             from rg_hip import lowp
             policy = getattr(opt, 'f8_scaling', 'delayed')
-            self._f8_states.append(lowp.set_conv_dtype(self.net_G, 'fp8', policy=policy))
+            # the layers that touch raw images / pose maps and the 3-channel output layers stay fp32 (usual fp8 practice: they
+            # hold < 2 % of the FLOPs and their quantisation noise goes straight into the image / the discriminator's verdict)
+            keep_G = ("block0.model.0", "source_encoder.block0.model.0", "outconv.conv1")
+            keep_D = ("block0.model.0", "block0.shortcut.1", "conv")
+            self._f8_states.append(lowp.set_conv_dtype(self.net_G, 'fp8', policy=policy, keep_fp32=keep_G))
             if self.gan_train:
-                self._f8_states.append(lowp.set_conv_dtype(self.net_D, 'fp8', policy=policy))
+                self._f8_states.append(lowp.set_conv_dtype(self.net_D, 'fp8', policy=policy, keep_fp32=keep_D))
 
         if getattr(self.opt, 'verbose', False):
             print('---------- Networks initialized -------------')

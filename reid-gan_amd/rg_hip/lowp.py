@@ -211,7 +211,7 @@ def set_conv_dtype(net, dtype, policy="delayed", keep_fp32=()):
     states = F8States(dev, capacity=max(16, 3 * len(convs)))
     states.policy = policy
     for name, m in convs:
-        if any(name == k or name.endswith("." + k) for k in keep_fp32):
+        if any(name == k or name == "module." + k for k in keep_fp32):
             continue
         m.__dict__["_rg_f8"] = F8Layer(states)
     states.finalize()

@@ -18,7 +18,7 @@ from oracle import ref_fp8 as R
 
 pytestmark = pytest.mark.gpu
 
-TOL_EMU = 2e-5
+TOL_EMU = 1e-4
 TOL_FWD_VS_FP32 = 6e-2
 TOL_BWD_VS_FP32 = 1e-1
 

@@ -73,6 +73,30 @@ def test_dptn_step(mode, with_vgg):
         _cmp(sub(pd[k].detach())[0], "dptn_%s_pd_%s" % (tag, k), 1e-4)
 
 
+def test_reference_step_is_sensitive_to_rounding():
+    """Why the GPU step test holds step-1 quantities and post-step parameters to 2e-2, not 1e-3: the reference arithmetic
+    itself, with its weights perturbed at the fp32 rounding level (3e-7 relative — another summation order does more), ends
+    two Adam steps 3e-3 .. 5e-3 (relative L2) away in the probed generator filters and 1e-3 away in the generated image,
+    because Adam's first updates are lr * sign(g) and a LeakyReLU branch flip perturbs every gradient below it."""
+    a, b = C.model("hinge", False), C.model("hinge", False)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in list(b.net_G.parameters()) + list(b.net_D.parameters()):
+            p.mul_(1 + 3e-7 * torch.randn(p.shape, generator=g))
+    d = C.inputs()
+    for step in range(2):
+        a.step(d)
+        b.step(d)
+        fa, fb = a.fake_image_t.detach(), b.fake_image_t.detach()
+        rel = ((fa - fb).norm() / fa.norm()).item()
+        assert rel <= (1e-5 if step == 0 else 2e-2)
+        if step == 1:
+            assert rel >= 1e-4, "the step is expected to amplify rounding-level differences (got %.1e)" % rel
+    pa, pb = dict(a.net_G.named_parameters()), dict(b.net_G.named_parameters())
+    worst = max(((pa[k] - pb[k]).norm() / pa[k].norm()).item() for k in C.PROBES_G)
+    assert 1e-3 <= worst <= 2e-2, worst
+
+
 def test_lsgan_fails_like_the_reference():
     m = C.model("lsgan", False)
     with pytest.raises(RuntimeError, match="scalar outputs"):
