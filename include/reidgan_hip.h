@@ -63,11 +63,16 @@ size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q
  * kernels walk the reduction (r,s)-major, so the padding test of the pixel gather happens once per 16-deep k-tile
  * (fwd, C % 16 == 0) and the weight operand of the data gradient is contiguous (float4 loads; K % 16 == 0,
  * C % 4 == 0); NULL selects the generic loaders.  Workspace: split-K scratch for layers too small to fill the chip
- * (dgrad: stride 1 only); a too-small workspace just disables the split.  Every tensor must be < 2 GiB. */
+ * (dgrad: stride 1 only); a too-small workspace just disables the split.  tile_counters (may be NULL): RG_TILE_COUNTERS
+ * ints of device memory, all zero on entry and all zero again when the launch has finished; with them the partial tiles of a
+ * split reduction are summed inside the launch by the last workgroup to arrive at each output tile (agent-scope release /
+ * acquire) instead of by a finishing launch.  The buffer must not be shared by launches that can run concurrently (one per
+ * stream).  Every tensor must be < 2 GiB. */
+#define RG_TILE_COUNTERS 16384
 int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y, int N, int C, int H, int W, int K,
                   int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
                   const float* residual, int act, float slope, void* workspace, size_t workspace_bytes,
-                  rg_stream_t stream);
+                  int* tile_counters, rg_stream_t stream);
 size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW);
 /* relu_mask (dgrad only, may be NULL): a tensor shaped like dx; after scale/shift/residual/act the result is zeroed where
  * relu_mask <= 0.  Passing the convolution's own forward INPUT (the ReLU output of the layer below) makes this the
@@ -75,7 +80,7 @@ size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int 
 int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K,
                     int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
                     const float* shift, const float* residual, int act, float slope, const float* relu_mask,
-                    float* rowsum, int rowsum_cols, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+                    float* rowsum, int rowsum_cols, void* workspace, size_t workspace_bytes, int* tile_counters, rg_stream_t stream);
 /* rowsum (dgrad only, may be NULL): [C][rowsum_cols] — per input channel, the sums of the FINAL dx values over blocks of
  * pixels (one column per class, pixel tile and wave column; fixed summation order).  Their sum over the columns is the
  * per-channel sum of dx: exactly the `partials` rg_bn_fold_wgrad of the layer below needs (dbeta / dgamma), so that layer does
@@ -91,6 +96,14 @@ size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,
                     rg_stream_t stream);
+/* the same for a convolution whose frozen-statistics BatchNorm is folded into it (FD-GAN's E and D_id, `set_bn_fix`,
+ * FD/fdgan/networks.py:57-60): dw = scale[k] * G with G = wgrad(x, g); dgamma[k] = invstd[k] * (sum w.G - mean[k] * sum_g[k]);
+ * sum_g directly or as n_slices partials per channel (then dbeta[k] = their sum is written too) */
+int rg_conv2d_wgrad_bnfold(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
+                           int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,
+                           const float* w, const float* scale, const float* invstd, const float* running_mean,
+                           const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma,
+                           rg_stream_t stream);
 
 /* ---- BatchNorm 1d/2d on [N][C][HW] ------------------------------------------------------------
  * Replaces nn.BatchNorm2d/1d (FD/fdgan/networks.py:26-35; resnet_ibn_a.py:75-81; FD/reid/models/
@@ -175,6 +188,9 @@ int rg_f8_roll_scales(float* states, int count, rg_stream_t stream);
  * gradient and -> [C][HW][Np] (b = c, r = n) for the weight gradient; filters [K][C][RS] -> [K][RS][Cp] and [C][RS][Kp] */
 int rg_f8_quantize(const float* in, void* out, float* state, float* scale_out, int fmt, int B, int R, int L, int64_t bs,
                    int64_t rs, rg_stream_t stream);
+/* both layouts of in[N][C][L] from ONE pass over the fp32 data: a [N][L][Cp] and b [C][L][Np] (either may be NULL) */
+int rg_f8_quantize_dual(const float* in, void* a, void* b, float* state, float* scale_out, int fmt, int N, int C, int L,
+                        rg_stream_t stream);
 /* y = act(sx*sw * conv(xq, wq) + shift[k] + residual); xq [N][H*W][Cp], wq [K][KH*KW][Cp] (e4m3), sx / sw: the quantiser's scale_out of each operand */
 int rg_conv2d_f8_fwd(const void* xq, const void* wq, const float* sx, const float* sw, int fmt_x, float* y, int N, int C,
                      int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* shift,

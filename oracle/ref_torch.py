@@ -500,9 +500,11 @@ class OFDGANStep(object):
     """FDGANModel step (FD/fdgan/model.py:100-229), stage-2 optimizer wiring by default, on the CPU."""
 
     def __init__(self, net_E, net_G, net_Di, net_Dp, lr=0.001, stage=2, lambda_recon=1.0, lambda_veri=1.0,
-                 lambda_sp=1.0):
+                 lambda_sp=1.0, smooth_label=False):
         self.net_E, self.net_G, self.net_Di, self.net_Dp = net_E, net_G, net_Di, net_Dp
         self.lr, self.stage = lr, stage
+        self.smooth = smooth_label                                  # _init_losses, model.py:90-98
+        self.rand_list = [True] * 1 + [False] * 10000 if smooth_label else [False]
         self.lam = (lambda_recon, lambda_veri, lambda_sp)
         if stage == 1:
             self.opt_G = torch.optim.Adam(net_G.parameters(), lr=lr * 0.1, betas=(0.5, 0.999))
@@ -526,6 +528,17 @@ class OFDGANStep(object):
             self.net_E.train()
             o_set_bn_eval(self.net_E)
 
+    def _d_loss(self, pred_real, pred_fake):
+        """model.py:165-171 / :178-184: one `random.choice` (label flip with p = 1/10001 when smoothing), then two GANLoss
+        calls, each of which draws (real, fake) smoothed labels (losses.py:20-22)"""
+        if random.choice(self.rand_list):
+            loss_real = o_gan_loss(pred_fake, True, self.smooth)
+            loss_fake = o_gan_loss(pred_real, False, self.smooth)
+        else:
+            loss_real = o_gan_loss(pred_real, True, self.smooth)
+            loss_fake = o_gan_loss(pred_fake, False, self.smooth)
+        return (loss_real + loss_fake) * 0.5
+
     def step(self, origin, target, posemap, labels, noise):
         """Inputs already in the post-set_input form (2b crops; labels [b]; noise [2b, nz])."""
         b2 = origin.shape[0]
@@ -536,14 +549,14 @@ class OFDGANStep(object):
         self.opt_Di.zero_grad()                                                      # backward_Di, :175-186
         _, _, pred_real = self.net_Di(origin, target)
         _, _, pred_fake = self.net_Di(origin, fake.detach())
-        loss_Di = (o_gan_loss(pred_real, True) + o_gan_loss(pred_fake, False)) * 0.5
+        loss_Di = self._d_loss(pred_real, pred_fake)
         loss_Di.backward()
         self.opt_Di.step()
 
         self.opt_Dp.zero_grad()                                                      # backward_Dp, :159-173
         pred_real = self.net_Dp(torch.cat((posemap, target), dim=1))
         pred_fake = self.net_Dp(torch.cat((posemap, fake.detach()), dim=1))
-        loss_Dp = (o_gan_loss(pred_real, True) + o_gan_loss(pred_fake, False)) * 0.5
+        loss_Dp = self._d_loss(pred_real, pred_fake)
         loss_Dp.backward()
         self.opt_Dp.step()
 
@@ -681,3 +694,41 @@ def dropout_keep_mask(n, p, seed):
     r = (z >> np.uint64(32)).astype(np.uint32)
     thr = np.uint32(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967295.0)))
     return torch.from_numpy((r >= thr))
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation: pairwise distances and the cascade second stage   FD/reid/evaluators.py:19-43,76-98,198-227
+# ------------------------------------------------------------------------------------------------
+def o_pairwise_distance(x, y):
+    """:90-98: |x|^2 + |y|^2 - 2 x y^T (addmm_)"""
+    m, n = x.size(0), y.size(0)
+    dist = torch.pow(x, 2).sum(dim=1, keepdim=True).expand(m, n) + torch.pow(y, 2).sum(dim=1, keepdim=True).expand(n, m).t()
+    return dist - 2 * x.mm(y.t())
+
+
+def o_cascade_second_stage(distmat, probe, gallery, embed_model, rerank_topk, embed_dist_fn=None):
+    """CascadeEvaluator.evaluate, :202-225, on feature matrices: per query, score the top-k gallery rows with the embedding
+    network (extract_embeddings :19-43: one call per query with a [1, D] probe broadcast against [k, D]), overwrite their
+    distances, then push everything outside the top-k behind them."""
+    import numpy as np
+    distmat = distmat.numpy().copy()
+    rank_indices = np.argsort(distmat, axis=1, kind="stable")
+    Q = distmat.shape[0]
+    embed_model.eval()
+    scores = []
+    with torch.no_grad():
+        for i in range(Q):
+            g = gallery[torch.as_tensor(rank_indices[i, :rerank_topk].copy())]
+            scores.append(embed_model(probe[i].view(1, -1), g))
+    embeddings = torch.cat(scores, 0).view(Q * rerank_topk, -1)
+    if embed_dist_fn is not None:
+        embeddings = embed_dist_fn(embeddings)
+    for k, embed in enumerate(embeddings):
+        i, j = k // rerank_topk, k % rerank_topk
+        distmat[i, rank_indices[i, j]] = float(embed)
+    for i, indices in enumerate(rank_indices):
+        bar = max(distmat[i][indices[:rerank_topk]])
+        gap = max(bar + 1. - distmat[i, indices[rerank_topk]], 0)
+        if gap > 0:
+            distmat[i][indices[rerank_topk:]] += gap
+    return distmat

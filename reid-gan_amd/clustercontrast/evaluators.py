@@ -1,19 +1,16 @@
 """Feature extraction and distance matrices of the evaluation / pseudo-labelling loops on the MI355X.
 
 Mirror of the numeric part of CC/clustercontrast/evaluators.py: `extract_cnn_feature` (:16-20), `extract_all_feature`
-(:22-27), `extract_features` (:30-68), `pairwise_distance` (:71-88) (FD/reid/evaluators.py:76-98 and
-FD/reid/feature_extraction/cnn.py:9-16 are the same functions).  CMC / mAP scoring, re-ranking and the `Evaluator` class
-are CPU-side metrics code and stay the reference's (evaluation metrics out of scope).
+(:22-27), `pairwise_distance` (:71-88) (FD/reid/evaluators.py:76-98 and FD/reid/feature_extraction/cnn.py:9-16 are the same
+functions).  The loader loop `extract_features` (:30-68), CMC / mAP scoring, re-ranking and the `Evaluator` class are host
+code and stay the reference's: with its tree behind this one on sys.path they are inherited at the bottom of
+this file and call the functions defined here.
 """
 from __future__ import print_function, absolute_import
-
-import time
-from collections import OrderedDict
 
 import torch
 
 from rg_hip import ops
-from .utils.meters import AverageMeter
 
 
 def _device():
@@ -36,40 +33,6 @@ def extract_all_feature(model, inputs):
     with torch.no_grad():
         outputs, extra_outputs = model(inputs, test_all=True)
     return outputs.data.cpu(), extra_outputs.data.cpu()
-
-
-def extract_features(model, data_loader, print_freq=50, extra_features=False):
-    model.eval()
-    batch_time = AverageMeter()
-    data_time = AverageMeter()
-    features = OrderedDict()
-    labels = OrderedDict()
-    gan_features = OrderedDict()
-    end = time.time()
-    with torch.no_grad():
-        for i, (imgs, fnames, pids, _, _) in enumerate(data_loader):
-            data_time.update(time.time() - end)
-            if extra_features:
-                outputs, extra_outputs = extract_all_feature(model, imgs)
-                for fname, output, extra_output, pid in zip(fnames, outputs, extra_outputs, pids):
-                    features[fname] = output
-                    gan_features[fname] = extra_output
-                    labels[fname] = pid
-            else:
-                outputs = extract_cnn_feature(model, imgs)
-                for fname, output, pid in zip(fnames, outputs, pids):
-                    features[fname] = output
-                    labels[fname] = pid
-            batch_time.update(time.time() - end)
-            end = time.time()
-            if (i + 1) % print_freq == 0:
-                print('Extract Features: [{}/{}]\t'
-                      'Time {:.3f} ({:.3f})\t'
-                      'Data {:.3f} ({:.3f})\t'
-                      .format(i + 1, len(data_loader), batch_time.val, batch_time.avg, data_time.val, data_time.avg))
-    if extra_features:
-        return features, gan_features, labels
-    return features, labels
 
 
 def _dist_block(x, y, xx_scale, with_y_norm):
@@ -99,7 +62,7 @@ def pairwise_distance(features, query=None, gallery=None):
     return dist_m.cpu(), x.numpy(), y.numpy()
 
 
-# `Evaluator`, `evaluate_all`, CMC / mAP and re-ranking are the reference's own (CPU) code: when its tree sits behind this
+# `extract_features`, `Evaluator`, `evaluate_all`, CMC / mAP and re-ranking are the reference's own (CPU) code: when its tree sits behind this
 # one on sys.path they are taken from there, and they call the functions above (rg_hip/overlay.py)
 from rg_hip.overlay import inherit as _rg_inherit  # noqa: E402
 _rg_inherit(globals())

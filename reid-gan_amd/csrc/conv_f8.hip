@@ -168,6 +168,77 @@ __global__ __launch_bounds__(256) void f8_quantize_transpose_kernel(const float*
     if (t == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(state + 1), __float_as_int(m));
 }
 
+
+// Both operand layouts of one tensor in ONE pass over the fp32 data: in[n][c][l] -> a[n][l][cp] and b[c][l][np] (cp / np: c / n
+// padded to 16 with zero bytes).  Tile = 16 n x 16 c x 64 l: the 256 (n, c) rows are read as coalesced float4 streams, the
+// quantised bytes are transposed through a 16 KiB LDS tile, and every thread emits one 16-byte store per (n, l) for `a` and per
+// (c, l) for `b`.  grid (l tiles, c tiles, n tiles).
+__global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __restrict__ in, unsigned char* __restrict__ a,
+                                                               unsigned char* __restrict__ b, float* __restrict__ state,
+                                                               float* __restrict__ scale_out, int fmt, int N, int C, int L,
+                                                               int Cp, int Np) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[16][16][64];     // [n][c][l]
+    __shared__ float red[16];
+    const int t = threadIdx.x;
+    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 16, n0 = blockIdx.z * 16;
+    const float amax = state[0];
+    const float fmax = f8_max(fmt);
+    const float q = amax > 0.f ? fmax / amax : 1.f;
+    if (scale_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *scale_out = amax > 0.f ? amax / fmax : 1.f;
+    float m = 0.f;
+    {
+        const int lq = t & 15, r0 = t >> 4;              // 16 lanes cover the 64 l of one (n, c) row; 16 rows per pass
+        const bool vec = (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int row = pass * 16 + r0;
+            const int n = n0 + (row >> 4), c = c0 + (row & 15);
+            const int l = l0 + 4 * lq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N && c < C) {
+                const float* src = in + ((int64_t)n * C + c) * L + l;
+                if (vec && l + 3 < L) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (l < L) v.x = src[0];
+                    if (l + 1 < L) v.y = src[1];
+                    if (l + 2 < L) v.z = src[2];
+                    if (l + 3 < L) v.w = src[3];
+                }
+            }
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            const unsigned w = pack4(fminf(fmaxf(v.x * q, -fmax), fmax), fminf(fmaxf(v.y * q, -fmax), fmax),
+                                     fminf(fmaxf(v.z * q, -fmax), fmax), fminf(fmaxf(v.w * q, -fmax), fmax), fmt);
+            *reinterpret_cast<unsigned*>(&tile[row >> 4][row & 15][4 * lq]) = w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                        // 1024 (x, l) pairs, 4 per thread
+        const int pr = k * 256 + t;
+        const int l = pr & 63, x = pr >> 6;              // x = n for layout a, = c for layout b
+        if (l0 + l >= L) continue;
+        if (a && n0 + x < N) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = (unsigned)tile[x][4 * j][l] | ((unsigned)tile[x][4 * j + 1][l] << 8) | ((unsigned)tile[x][4 * j + 2][l] << 16) |
+                       ((unsigned)tile[x][4 * j + 3][l] << 24);
+            *reinterpret_cast<uint4*>(a + ((int64_t)(n0 + x) * L + l0 + l) * Cp + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (b && c0 + x < C) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = (unsigned)tile[4 * j][x][l] | ((unsigned)tile[4 * j + 1][x][l] << 8) | ((unsigned)tile[4 * j + 2][x][l] << 16) |
+                       ((unsigned)tile[4 * j + 3][x][l] << 24);
+            *reinterpret_cast<uint4*>(b + ((int64_t)(c0 + x) * L + l0 + l) * Np + n0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    m = rg_block_max(m, red);
+    if (t == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(state + 1), __float_as_int(m));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // GEMM core
 // ---------------------------------------------------------------------------------------------------------------
@@ -517,6 +588,20 @@ extern "C" int rg_f8_quantize(const float* in, void* out, float* state, float* s
     hipLaunchKernelGGL(f8_quantize_transpose_kernel, dim3(rg::cdiv(L, 64), rg::cdiv(Rp, 64), B), dim3(256), 0, stream, in,
                        static_cast<unsigned char*>(out), state, scale_out, fmt, R, L, Rp, bs, rs);
     return rg::check_launch("rg_f8_quantize");
+}
+
+// Both layouts of in[N][C][L] in one pass: a [N][L][Cp] (may be NULL) and b [C][L][Np] (may be NULL); see rg_f8_quantize.
+// Padding rows of `a` beyond C and of `b` beyond N are written as zeros only inside the 16-wide tiles that hold real data; callers
+// allocate exactly Cp = 16*ceil(C/16), Np = 16*ceil(N/16), which those tiles cover.
+extern "C" int rg_f8_quantize_dual(const float* in, void* a, void* b, float* state, float* scale_out, int fmt, int N, int C, int L,
+                                   hipStream_t stream) {
+    RG_REQUIRE(in && (a || b) && state && (fmt == 0 || fmt == 1) && N > 0 && C > 0 && L > 0, "rg_f8_quantize_dual: bad arguments");
+    const int Cp = pad16(C), Np = pad16(N);
+    RG_REQUIRE(Cp / 16 <= 65535 && Np / 16 <= 65535, "rg_f8_quantize_dual: dimension exceeds the grid limit");
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, (double)L * (4.0 * N * C + (a ? (double)N * Cp : 0.0) + (b ? (double)C * Np : 0.0)));
+    hipLaunchKernelGGL(f8_quantize_dual_kernel, dim3(rg::cdiv(L, 64), Cp / 16, Np / 16), dim3(256), 0, stream, in,
+                       static_cast<unsigned char*>(a), static_cast<unsigned char*>(b), state, scale_out, fmt, N, C, L, Cp, Np);
+    return rg::check_launch("rg_f8_quantize_dual");
 }
 
 // ---- forward: y[N][K][P][Q] fp32 = act(sx * sw * conv(xq, wq) + shift + residual) ------------------------------------

@@ -67,112 +67,96 @@ class FDGANModel(object):
             print_network(self.net_Dp)
             print('-----------------------------------------------')
 
+    # ---- construction -----------------------------------------------------------------------------------------------
+    # What is built is the reference's (FD/fdgan/model.py:39-125): E = Siamese(ResNet trunk, 2-way embedding), G, D_id =
+    # Siamese(ResNet trunk, 1-way embedding), D_pd = PatchGAN on image + 18 pose channels; stage 1 trains G and the two
+    # discriminators on a frozen E, stage 2 everything.  It is organised by what each stage needs rather than by network.
+    _STAGE = {
+        #        trainable BatchNorm-frozen nets            checkpoint attribute per network (None: initialised, not loaded)
+        1: dict(bn_fixed=("Di",), eval_nets=("E",), ckpt=dict(E="netE_pretrain", Di="netE_pretrain", G=None, Dp=None),
+                lr_scale=dict(G=0.1, Di=0.01, Dp=1.0)),
+        2: dict(bn_fixed=("E", "Di"), eval_nets=(), ckpt=dict(E="netE_pretrain", G="netG_pretrain", Di="netDi_pretrain",
+                                                                Dp="netDp_pretrain"),
+                lr_scale=dict(G=0.1, Di=1.0, Dp=1.0)),
+    }
+
+    def _siamese(self, num_classes):
+        pretrained = bool(getattr(self.opt, "imagenet_pretrained", False))
+        trunk = create(self.opt.arch, cut_at_pooling=True, pretrained=pretrained)
+        return SiameseNet(trunk, EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048,
+                                                 num_classes=num_classes))
+
     def _init_models(self):
         opt = self.opt
-        pretrained = bool(getattr(opt, "imagenet_pretrained", False))
-        self.net_G = CustomPoseGenerator(opt.pose_feature_size, 2048, opt.noise_feature_size,
-                                         dropout=opt.drop, norm_layer=self.norm_layer, fuse_mode=opt.fuse_mode,
-                                         connect_layers=opt.connect_layers)
-        e_base_model = create(opt.arch, cut_at_pooling=True, pretrained=pretrained)
-        e_embed_model = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=2)
-        self.net_E = SiameseNet(e_base_model, e_embed_model)
-
-        di_base_model = create(opt.arch, cut_at_pooling=True, pretrained=pretrained)
-        di_embed_model = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=1)
-        self.net_Di = SiameseNet(di_base_model, di_embed_model)
-        self.net_Dp = NLayerDiscriminator(3 + 18, norm_layer=self.norm_layer)
-
+        if opt.stage not in self._STAGE:
+            raise ValueError("unknown training stage %r" % (opt.stage,))
+        nets = dict(
+            G=CustomPoseGenerator(opt.pose_feature_size, 2048, opt.noise_feature_size, dropout=opt.drop,
+                                  norm_layer=self.norm_layer, fuse_mode=opt.fuse_mode, connect_layers=opt.connect_layers),
+            E=self._siamese(2), Di=self._siamese(1), Dp=NLayerDiscriminator(3 + 18, norm_layer=self.norm_layer))
         random_init = bool(getattr(opt, "random_init", False))      # synthetic benchmarks / tests: no checkpoints
-        if opt.stage == 1:
-            init_weights(self.net_G)
-            init_weights(self.net_Dp)
-            if not random_init:
-                state_dict = remove_module_key(torch.load(opt.netE_pretrain, map_location="cpu"))
-                self.net_E.load_state_dict(state_dict)
-                state_dict = dict(state_dict)
-                state_dict['embed_model.classifier.weight'] = state_dict['embed_model.classifier.weight'][1:2]
-                state_dict['embed_model.classifier.bias'] = state_dict['embed_model.classifier.bias'][1:2]
-                self.net_Di.load_state_dict(state_dict)
-        elif opt.stage == 2:
-            if random_init:
-                init_weights(self.net_G)
-                init_weights(self.net_Dp)
-            else:
-                self._load_state_dict(self.net_E, opt.netE_pretrain)
-                self._load_state_dict(self.net_G, opt.netG_pretrain)
-                self._load_state_dict(self.net_Di, opt.netDi_pretrain)
-                self._load_state_dict(self.net_Dp, opt.netDp_pretrain)
-        else:
-            assert ('unknown training stage')
-
-        self.net_E = DataParallel(self.net_E).to(self.device)
-        self.net_G = DataParallel(self.net_G).to(self.device)
-        self.net_Di = DataParallel(self.net_Di).to(self.device)
-        self.net_Dp = DataParallel(self.net_Dp).to(self.device)
+        for name, attr in self._STAGE[opt.stage]["ckpt"].items():
+            if attr is None or (random_init and name in ("G", "Dp")):
+                init_weights(nets[name])
+            elif not random_init:
+                state = remove_module_key(torch.load(getattr(opt, attr), map_location="cpu"))
+                if opt.stage == 1 and name == "Di":
+                    # D_id starts from E with the 'same identity' row of its 2-way classifier (:56-57; kept [1, 2048])
+                    state = dict(state)
+                    for key in ("embed_model.classifier.weight", "embed_model.classifier.bias"):
+                        state[key] = state[key][1:2]
+                nets[name].load_state_dict(state)
+        for name, net in nets.items():
+            setattr(self, "net_" + name, DataParallel(net).to(self.device))
 
     def reset_model_status(self):
-        if self.opt.stage == 1:
-            self.net_G.train()
-            self.net_Dp.train()
-            self.net_E.eval()
-            self.net_Di.train()
-            self.net_Di.apply(set_bn_fix)
-        elif self.opt.stage == 2:
-            self.net_E.train()
-            self.net_G.train()
-            self.net_Di.train()
-            self.net_Dp.train()
-            self.net_E.apply(set_bn_fix)
-            self.net_Di.apply(set_bn_fix)
+        plan = self._STAGE[self.opt.stage]
+        for name in ("E", "G", "Di", "Dp"):
+            net = getattr(self, "net_" + name)
+            net.eval() if name in plan["eval_nets"] else net.train()
+        for name in plan["bn_fixed"]:
+            getattr(self, "net_" + name).apply(set_bn_fix)
 
     def _load_state_dict(self, net, path):
-        state_dict = remove_module_key(torch.load(path, map_location="cpu"))
-        net.load_state_dict(state_dict)
+        net.load_state_dict(remove_module_key(torch.load(path, map_location="cpu")))
 
     def _init_losses(self):
-        if self.opt.smooth_label:
-            self.criterionGAN_D = GANLoss(smooth=True)
-            self.rand_list = [True] * 1 + [False] * 10000
-        else:
-            self.criterionGAN_D = GANLoss(smooth=False)
-            self.rand_list = [False]
+        smooth = bool(self.opt.smooth_label)
+        self.criterionGAN_D = GANLoss(smooth=smooth)
         self.criterionGAN_G = GANLoss(smooth=False)
+        # label flip for the discriminators: one draw in 10001 when smoothing, never otherwise (:90-98)
+        self.rand_list = [True] + [False] * 10000 if smooth else [False]
 
     def _init_optimizers(self):
         opt = self.opt
-        if opt.stage == 1:
-            self.optimizer_G = roptim.Adam(self.net_G.parameters(), lr=opt.lr * 0.1, betas=(0.5, 0.999))
-            self.optimizer_Di = roptim.SGD(self.net_Di.parameters(), lr=opt.lr * 0.01, momentum=0.9, weight_decay=1e-4)
-            self.optimizer_Dp = roptim.SGD(self.net_Dp.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
-        elif opt.stage == 2:
+        scale = self._STAGE[opt.stage]["lr_scale"]
+        if opt.stage == 2:
             # `lr_mult` is carried in the groups but never applied, exactly as in the reference (:109-113)
-            param_groups = [{'params': self.net_E.module.base_model.parameters(), 'lr_mult': 0.1},
-                            {'params': self.net_E.module.embed_model.parameters(), 'lr_mult': 1.0},
-                            {'params': self.net_G.parameters(), 'lr_mult': 0.1}]
-            self.optimizer_G = roptim.Adam(param_groups, lr=opt.lr * 0.1, betas=(0.5, 0.999))
-            self.optimizer_Di = roptim.SGD(self.net_Di.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
-            self.optimizer_Dp = roptim.SGD(self.net_Dp.parameters(), lr=opt.lr, momentum=0.9, weight_decay=1e-4)
-
-        self.schedulers = []
-        self.optimizers = []
-        self.optimizers.append(self.optimizer_G)
-        self.optimizers.append(self.optimizer_Di)
-        self.optimizers.append(self.optimizer_Dp)
-        for optimizer in self.optimizers:
-            self.schedulers.append(get_scheduler(optimizer, opt))
-        # data-parallel gradient reduction (no-op unless torch.distributed is initialised)
-        # (rank 0's parameters and buffers are broadcast once here, as DataParallel's replicate() does on every call)
-        g_nets = [self.net_G] + ([self.net_E] if opt.stage == 2 else [])
+            g_params = [{'params': self.net_E.module.base_model.parameters(), 'lr_mult': 0.1},
+                        {'params': self.net_E.module.embed_model.parameters(), 'lr_mult': 1.0},
+                        {'params': self.net_G.parameters(), 'lr_mult': 0.1}]
+            g_nets = [self.net_G, self.net_E]
+        else:
+            g_params, g_nets = self.net_G.parameters(), [self.net_G]
+        self.optimizer_G = roptim.Adam(g_params, lr=opt.lr * scale["G"], betas=(0.5, 0.999))
+        self.optimizer_Di = roptim.SGD(self.net_Di.parameters(), lr=opt.lr * scale["Di"], momentum=0.9, weight_decay=1e-4)
+        self.optimizer_Dp = roptim.SGD(self.net_Dp.parameters(), lr=opt.lr * scale["Dp"], momentum=0.9, weight_decay=1e-4)
+        self.optimizers = [self.optimizer_G, self.optimizer_Di, self.optimizer_Dp]
+        self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
+        # data-parallel gradient reduction (no-op unless torch.distributed is initialised); rank 0's parameters and
+        # buffers are broadcast once here, as DataParallel's replicate() does on every call
         self.reducers = [GradReducer(self.optimizer_G, modules=g_nets),
                          GradReducer(self.optimizer_Di, modules=[self.net_Di]),
                          GradReducer(self.optimizer_Dp, modules=[self.net_Dp])]
         if self.reducers[0].active():
-            g_params = list(self.net_G.parameters())
-            self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_params)
+            g_list = list(self.net_G.parameters())
+            self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_list)
 
     def _aux_stream(self):
-        """Second HIP stream for work that is independent of the main chain (RG_AUX_STREAM=0 disables it)."""
-        if os.environ.get("RG_AUX_STREAM", "1") == "0":
+        """Second HIP stream for work that is independent of the main chain (RG_AUX_STREAM=0 disables it).  With label
+        smoothing the two discriminator passes draw from Python's `random` (GANLoss, label flip): they then run in the
+        reference's order on one stream so that a seeded run consumes the generator exactly like the reference."""
+        if os.environ.get("RG_AUX_STREAM", "1") == "0" or self.opt.smooth_label:
             return None
         s = getattr(self, "_aux", None)
         if s is None:

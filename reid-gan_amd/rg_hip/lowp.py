@@ -155,6 +155,18 @@ def conv_wgrad(xq_chwn, dyq_chwn, geom, out=None):
     return dw
 
 
+def quantize_dual(x, state, want_a=True, want_b=True):
+    """(QTensor 'nhwc' [N][L][Cp] or None, QTensor 'chwn' [C][L][Np] or None) from ONE pass over the fp32 tensor"""
+    x = _chk(x, "x")
+    N, C = x.shape[0], x.shape[1]
+    L = x.numel() // (N * C)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    a = torch.empty((N, L, pad16(C)), dtype=torch.uint8, device=x.device) if want_a else None
+    b = torch.empty((C, L, pad16(N)), dtype=torch.uint8, device=x.device) if want_b else None
+    lib.rg_f8_quantize_dual(_p(x), _p(a), _p(b), state.ptr, _p(scale), state.fmt, N, C, L, _stream())
+    return (QTensor(a, scale, state.fmt) if want_a else None, QTensor(b, scale, state.fmt) if want_b else None)
+
+
 class F8Layer(object):
     """Scaling states and the cached quantised filters of one convolution layer."""
 
@@ -172,23 +184,20 @@ class F8Layer(object):
 
     def quant_act_both(self, x, want_chwn):
         self.sx.prepare(x)
-        a = quantize(x, self.sx, "nhwc")
-        b = quantize(x, self.sx, "chwn", a.scale) if want_chwn else None
-        return a, b
+        return quantize_dual(x, self.sx, True, want_chwn)
 
     def quant_grad_both(self, dy, want_nhwc, want_chwn):
         self.sdy.prepare(dy)
-        a = quantize(dy, self.sdy, "nhwc") if want_nhwc else None
-        b = quantize(dy, self.sdy, "chwn", a.scale if a is not None else None) if want_chwn else None
-        return a, b
+        return quantize_dual(dy, self.sdy, want_nhwc, want_chwn)
 
     def weights(self, w, key=None):
         """(wq [K][RS][Cp], wq_t [C][RS][Kp]) of the filter tensor, re-quantised (always with a fresh amax: filters are
         small) when `key` changes; key=None: every call (spectral-normed filters change every forward)."""
         if key is None or key != self._wkey:
-            self.sw.prepare(w, force_jit=True)
-            a = quantize(w, self.sw, "krsc")
-            self._wq = (a, quantize(w, self.sw, "crsk", a.scale))
+            # filters change by one optimizer step between uses: the previous step's maximum scales them (delayed policy);
+            # 'jit' measures first
+            self.sw.prepare(w)
+            self._wq = quantize_dual(w, self.sw, True, True)
             self._wkey = key
         return self._wq
 

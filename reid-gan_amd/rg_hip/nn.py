@@ -527,11 +527,16 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
         og = tape.grad_out(bn.weight) if want_g else None
         dgamma = (og if og is not None else torch.empty_like(f.scale)) if want_g else None
 
-        def finish(G):
-            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
-                              dbeta=dbeta if part is not None else None)
+        # the pair's finishing pass (dw = scale * G, dgamma, dbeta from the slice partials) rides on the split-K sum
+        fold = dict(w=w, scale=f.scale, invstd=f.invstd, mean=bn.running_mean, sum_g=sg, partials=part,
+                    dbeta=dbeta if part is not None else None, dgamma=dgamma)
+        if conv.weight.shape[0] == 1 and conv.weight.shape[2] * conv.weight.shape[3] > 1:
+            fold, after = None, (lambda G: ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
+                                                             dbeta=dbeta if part is not None else None))
+        else:
+            after = None
         dw = ops.conv2d_wgrad(x, g, conv.weight.shape, conv.stride, conv.padding,
-                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=finish)
+                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=after, bnfold=fold)
         if want_w:
             tape.add_grad(conv.weight, dw)
         if want_g:

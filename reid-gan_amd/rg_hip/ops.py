@@ -60,6 +60,24 @@ class _Workspace(object):
 _ws = _Workspace()
 
 
+class _TileCounters(object):
+    """Arrival counters of the in-kernel split-K reductions (rg_conv2d_fwd / dgrad `tile_counters`): RG_TILE_COUNTERS zero
+    ints per (device, stream) — launches on one stream are ordered and every launch leaves the buffer zero."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, device):
+        key = (device.index, _stream())
+        buf = self.bufs.get(key)
+        if buf is None:
+            buf = self.bufs[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+        return buf
+
+
+_tc = _TileCounters()
+
+
 _ws_sizes = {}
 
 
@@ -115,7 +133,8 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
     nbytes = _ws_query("rg_conv2d_fwd_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device) if nbytes else None
     lib.rg_conv2d_fwd(_p(x), _p(w), _p(w_krsc), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
-                      _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
+                      _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0,
+                      _p(_tc.get(x.device)) if ws is not None else None, _stream())
     return y
 
 
@@ -150,7 +169,7 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
             rowsum = torch.empty((C, cols), dtype=torch.float32, device=dy.device)
     lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(w_krsc), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale),
                         _p(shift), _p(residual), act, slope, _p(relu_mask), _p(rowsum), cols, _p(ws),
-                        ws.numel() if ws is not None else 0, _stream())
+                        ws.numel() if ws is not None else 0, _p(_tc.get(dy.device)) if ws is not None else None, _stream())
     if rowsum is not None:
         dx._rg_rowsum = rowsum          # rides with the gradient to the BatchNorm fold of the layer below (nn.conv_bn_tb)
     return dx
@@ -214,9 +233,10 @@ def side_join():
         sess.used = False
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None, bnfold=None):
     """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
-    behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
+    behind the wgrad kernels on the same stream.  bnfold = dict(w, scale, invstd, mean, sum_g | partials, dbeta, dgamma):
+    the finishing pass of a (conv, frozen BatchNorm) pair rides on the split-K sum (rg_conv2d_wgrad_bnfold)."""
     if side and _SIDE["on"]:
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
@@ -226,8 +246,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
             ev.record(main)
             sess.stream.wait_event(ev)
             with torch.cuda.stream(sess.stream):
-                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after)
-            sess.refs.append((x, dy, dw, after))         # the hook's closure keeps ITS operands alive too
+                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after, bnfold=bnfold)
+            sess.refs.append((x, dy, dw, after, bnfold))  # hooks / fold operands stay alive until the join
             sess.used = True
             return dw
     x, dy = _chk(x, "x"), _chk(dy, "dy")
@@ -241,8 +261,15 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     nbytes = _ws_query("rg_conv2d_wgrad_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device)
-    lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
-                        _stream())
+    if bnfold is not None:
+        part = bnfold.get("partials")
+        lib.rg_conv2d_wgrad_bnfold(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
+                                   _p(bnfold["w"]), _p(bnfold["scale"]), _p(bnfold["invstd"]), _p(bnfold["mean"]),
+                                   _p(bnfold.get("sum_g")), _p(part), part.shape[1] if part is not None else 0,
+                                   _p(bnfold.get("dbeta")), _p(bnfold.get("dgamma")), _stream())
+    else:
+        lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
+                            _stream())
     if after is not None:
         after(dw)
     return dw

@@ -1,0 +1,237 @@
+"""Exactness of the kernel compositions (parity items 6a / 6b).
+
+(a) Kink-free comparisons.  Two exact fp32 implementations of a ReLU network agree only up to "a few elements took the other
+branch" (pre-activations differ by ~1e-6, so ~1 element per layer does), which forces the kinked gradient tests onto L2
+tolerances of 1e-2.  Here the kinks are taken out of play on BOTH sides, so every gradient must agree with an fp64 run of the
+oracle in the MAX norm at rounding level (2e-5 of the tensor's largest entry):
+  * ResNet-50 trunk, eval-mode and train-mode BatchNorm: every BatchNorm bias is set to +8 (weights ~1), which puts every
+    pre-ReLU value > 0 — the SAME fused programs run (BatchNorm folded into the conv epilogues / train-mode statistics, ReLU
+    masks in the dgrad epilogues, residual adds), their masks simply never bite.  Max-pool keeps its argmax kink: the stem's
+    conv1 / bn1 gradients get 2e-3 (one window whose two largest values lie within rounding moves one of ~5e5 terms);
+  * CustomPoseGenerator (train-mode BatchNorm): the same shift, positive pose maps / noise and |w| in the norm-less first
+    layer keep its LeakyReLU(0.2) / ReLU inputs positive;
+  * PoseGenerator1 and ResDiscriminator (module-level LeakyReLU): slope 1.
+(b) HIP outputs against the committed reference fixtures directly (tests/golden/reference_modules.npz, same cases.py inputs).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as O
+from tests.golden import cases as C
+from tests.golden.cases import sub
+from tests.test_modules_gpu import _check
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_modules.npz"))
+
+
+def _shift_bn(mod, shift=8.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for m in mod.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+            with torch.no_grad():
+                m.bias.fill_(shift)
+                m.weight.copy_(1.0 + 0.1 * torch.rand(m.weight.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.8 + 0.4 * torch.rand(m.running_var.shape, generator=g))
+
+
+def _grads_exact(rg, o64, tol=2e-5, loose=(), loose_tol=2e-3):
+    og = dict(o64.named_parameters())
+    gmax = max(p.grad.abs().max().item() for p in og.values() if p.grad is not None)
+    worst = 0.0
+    for n, p in rg.named_parameters():
+        ref = og[n].grad
+        if ref is None:
+            assert p.grad is None, n
+            continue
+        assert p.grad is not None, n
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        err = (p.grad.detach().double().cpu() - ref).abs().max().item() / scale
+        t = loose_tol if any(n.startswith(k) or ("." + k) in n for k in loose) else tol
+        assert err <= t, "%s: max-norm err %.3e > %.1e" % (n, err, t)
+        if t == tol:
+            worst = max(worst, err)
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_resnet50_trunk_exact_without_kinks(dev, mode):
+    import reid.models as RM
+    torch.manual_seed(40)
+    o = O.OReidResNet(50, cut_at_pooling=True)
+    _shift_bn(o, 8.0, 1)
+    r = RM.create('resnet50', cut_at_pooling=True, pretrained=False)
+    r.load_state_dict(o.state_dict())
+    r.to(dev)
+    o = o.double()
+    getattr(o, mode)()
+    getattr(r, mode)()
+    x = O.synth_images(4, 64, 32, seed=3)
+    xo = x.double().clone().requires_grad_(True)
+    xr = x.clone().to(dev).requires_grad_(True)
+    yo, yr = o(xo), r(xr)
+    assert float(yo.min()) > 0
+    _check(yr, yo, 2e-5, "features")
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(yo.shape, generator=g)
+    (yo * cot.double()).sum().backward()
+    (yr * cot.to(dev)).sum().backward()
+    # the stem sits behind the max-pool (argmax kink): its filter / BN gradients and dx get the looser bound
+    worst = _grads_exact(r, o, loose=("base.conv1", "base.bn1"))
+    err_dx = (xr.grad.double().cpu() - xo.grad).abs().max().item() / xo.grad.abs().max().item()
+    assert err_dx <= 2e-3, err_dx
+    print("trunk (%s BN): worst gradient max-norm error %.2e, dx %.2e" % (mode, worst, err_dx))
+
+
+def test_pose_generator_exact_without_kinks(dev):
+    import fdgan.networks as N
+    torch.manual_seed(10)
+    o = O.OPoseGenerator(128, 2048, 256, dropout=0.0, norm='batch', connect_layers=0)
+    o.apply(O.o_weights_init_normal)
+    _shift_bn(o, 8.0, 2)
+    with torch.no_grad():
+        o.en_conv1[0].weight.abs_()                       # no norm behind it: positive filters on positive pose maps
+    r = N.CustomPoseGenerator(128, 2048, 256, dropout=0.0, norm_layer=N.get_norm_layer('batch'), fuse_mode='cat',
+                              connect_layers=0)
+    r.load_state_dict(o.state_dict())
+    r.to(dev).train()
+    o = o.double().train()
+    g = torch.Generator().manual_seed(4)
+    pose = O.synth_posemaps(3, seed=3) + 0.5
+    feat = torch.randn(3, 2048, 1, 1, generator=g).abs() + 0.1
+    z = torch.randn(3, 256, 1, 1, generator=g).abs() + 0.1
+    fo = feat.double().clone().requires_grad_(True)
+    fr = feat.clone().to(dev).requires_grad_(True)
+    yo = o(pose.double(), fo, z.double())
+    yr = r(pose.to(dev), fr, z.to(dev))
+    _check(yr, yo, 2e-5, "fake")
+    cot = torch.randn(yo.shape, generator=g)
+    (yo * cot.double()).sum().backward()
+    (yr * cot.to(dev)).sum().backward()
+    _check(fr.grad, fo.grad, 2e-5, "d reid feature")
+    worst = _grads_exact(r, o)
+    print("CustomPoseGenerator: worst gradient max-norm error %.2e" % worst)
+
+
+def test_dualgan_nets_exact_without_kinks(dev):
+    from dual_gan.models import networks as N
+    from tests.golden import cases_dualgan as CD
+    from tests.test_dptn_gpu import _remove_kinks
+    # PoseGenerator1
+    on, (feat, pose) = CD.posegen1_case()
+    rg = N.PoseGenerator1(64, 18, 256, 3, 'instance', 'LeakyReLU', False, False, 3, True, 2, 2, 2)
+    rg.load_state_dict(on.state_dict())
+    rg.to(dev).train()
+    _remove_kinks([rg], [on])
+    on = on.double()
+    fo = feat.double().clone().requires_grad_(True)
+    fr = feat.clone().to(dev).requires_grad_(True)
+    yo, yr = on(fo, pose.double()), rg(fr, pose.to(dev))
+    _check(yr, yo, 2e-5, "posegen1 fwd")
+    g = torch.Generator().manual_seed(5)
+    cot = torch.randn(yo.shape, generator=g)
+    (yo * cot.double()).sum().backward()
+    (yr * cot.to(dev)).sum().backward()
+    _check(fr.grad, fo.grad, 5e-5, "posegen1 d feature")
+    w1 = _grads_exact(rg, on, tol=1e-4)
+    # ResDiscriminator (spectral norm: both sides run the same power iteration)
+    od, x = CD.resdisc_case()
+    rd = N.ResDiscriminator(3, 32, 128, 3, 'none', 'LeakyReLU', True)
+    rd.load_state_dict(od.state_dict())
+    rd.to(dev).train()
+    _remove_kinks([rd], [od])
+    od = od.double()
+    xo = x.double().clone().requires_grad_(True)
+    xr = x.clone().to(dev).requires_grad_(True)
+    yo, yr = od(xo), rd(xr)
+    _check(yr, yo, 2e-5, "resdisc fwd")
+    (yo ** 2).mean().backward()
+    (yr ** 2).mean().backward()
+    _check(xr.grad, xo.grad, 5e-5, "resdisc dx")
+    w2 = _grads_exact(rd, od, tol=1e-4)
+    print("PoseGenerator1 / ResDiscriminator: worst gradient max-norm errors %.2e / %.2e" % (w1, w2))
+
+
+# ---- (b) the committed reference fixtures, directly ---------------------------------------------------------------------
+def _gold(got, key, tol=1e-3):
+    ref = GOLD[key]
+    got = np.asarray(got, dtype=np.float64).reshape(ref.shape)
+    err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+    assert err <= tol, "%s: %.3e" % (key, err)
+
+
+@pytest.mark.parametrize("cl", [0, 2])
+def test_generator_vs_reference_fixture(dev, cl):
+    import fdgan.networks as N
+    og, (pose, feat, z) = C.generator_case(cl)
+    r = N.CustomPoseGenerator(128, 2048, 256, dropout=0.0, norm_layer=N.get_norm_layer('batch'), fuse_mode='cat',
+                              connect_layers=cl)
+    r.load_state_dict(og.state_dict())
+    r.to(dev).train()
+    s, st = sub(r(pose.to(dev), feat.to(dev), z.to(dev)).cpu())
+    _gold(s, "g_fwd_cl%d" % cl)
+    ref = GOLD["g_fwd_cl%d_stats" % cl]
+    assert abs(st[1] - ref[1]) <= 1e-3 * abs(ref[1]) and st[2] == ref[2]
+
+
+@pytest.mark.parametrize("norm,key", [("batch", "dp_fwd"), ("instance", "dp_in_fwd")])
+def test_discriminator_vs_reference_fixture(dev, norm, key):
+    import fdgan.networks as N
+    od, x = C.discriminator_case(norm)
+    r = N.NLayerDiscriminator(21, norm_layer=N.get_norm_layer(norm))
+    r.load_state_dict(od.state_dict())
+    r.to(dev)
+    r.train(od.training)
+    s, _ = sub(r(x.to(dev)).cpu())
+    _gold(s, key)
+
+
+def test_embed_ganloss_gem_vs_reference_fixture(dev):
+    from fdgan.losses import GANLoss
+    from reid.models.embedding import EltwiseSubEmbed
+    from clustercontrast.models.pooling import GeneralizedMeanPoolingP
+    oe, (f1, f2) = C.embed_case()
+    e = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=2048, num_classes=2)
+    e.load_state_dict(oe.state_dict())
+    e.to(dev)
+    for mode in ("train", "eval"):
+        getattr(e, mode)()
+        _gold(e(f1.to(dev), f2.to(dev)).detach().cpu().numpy(), "embed_" + mode)
+    pred = C.ganloss_case().to(dev)
+    _gold([float(GANLoss()(pred, True)), float(GANLoss()(pred, False))], "ganloss")
+    _, x, dy = C.gem_case()
+    gem = GeneralizedMeanPoolingP().to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = gem(xd)
+    y.backward(dy.to(dev).view_as(y))
+    _gold(y.detach().cpu().numpy(), "gem_fwd")
+    _gold(sub(xd.grad.cpu())[0], "gem_dx")
+    _gold(gem.p.grad.cpu().numpy(), "gem_dp")
+
+
+def test_trunk_and_cluster_memory_vs_reference_fixture(dev):
+    import reid.models as RM
+    from clustercontrast.models.cm import cm, cm_hard
+    oreid, trunk_sd, imgs = C.trunk_case()
+    r = RM.create('resnet50', cut_at_pooling=True, pretrained=False)
+    r.load_state_dict(oreid.state_dict())
+    r.to(dev)
+    for mode in ("eval", "train"):
+        getattr(r, mode)()
+        s, _ = sub(r(imgs.to(dev)).detach().cpu())
+        _gold(s, "resnet50_trunk_%s" % mode)
+        r.base.load_state_dict(trunk_sd)
+    bank, feats, labels, gout = C.cm_case()
+    for fn, tag in ((cm, "cm"), (cm_hard, "cm_hard")):
+        b = bank.clone().to(dev)
+        x = feats.clone().to(dev).requires_grad_(True)
+        y = fn(x, labels.to(dev), b, 0.2)
+        y.backward(gout.to(dev))
+        _gold(sub(y.detach().cpu())[0], tag + "_logits")
+        _gold(sub(x.grad.cpu())[0], tag + "_grad")
+        _gold(sub(b.cpu(), 2048)[0], tag + "_bank")

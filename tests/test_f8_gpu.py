@@ -60,6 +60,13 @@ def test_quantizer_bit_exact(dev, fmt, shape):
     xq, d = R.quantize(x, amax, fmt)
     assert torch.equal(qa.buf.cpu(), R.to_layout(xq, "nhwc")), "nhwc bytes differ"
     assert torch.equal(qb.buf.cpu(), R.to_layout(xq, "chwn")), "chwn bytes differ"
+    # the single-pass form (what the layers use): both layouts from one read of the fp32 tensor
+    da, db = lowp.quantize_dual(xd, s)
+    torch.cuda.synchronize()
+    assert torch.equal(da.buf.cpu(), qa.buf.cpu()) and torch.equal(db.buf.cpu(), qb.buf.cpu()), "dual-layout pass differs"
+    assert float(da.scale.cpu()) == float(d)
+    only_b = lowp.quantize_dual(xd, s, want_a=False)[1]
+    assert torch.equal(only_b.buf.cpu(), qb.buf.cpu())
     assert float(qa.scale.cpu()) == float(d)
     state = s.view().cpu()
     assert float(state[0]) == float(amax) and float(state[1]) == float(amax) and float(state[3]) == R.FMAX[fmt]

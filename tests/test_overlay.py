@@ -29,8 +29,10 @@ def test_reference_tree_behind_this_one(tmp_path):
     _write(ref, "clustercontrast/datasets.py", "NAMES = ['market1501']\n")
     _write(ref, "clustercontrast/models/__init__.py", "raise RuntimeError('the reference models package must not be imported')\n")
     _write(ref, "clustercontrast/evaluators.py", """
+        def extract_cnn_feature(model, inputs):
+            return 'reference extract_cnn_feature'
         def extract_features(model, loader):
-            return 'reference extract_features'
+            return extract_cnn_feature(model, None)
         def pairwise_distance(features, query=None, gallery=None):
             return 'reference pairwise_distance'
         class Evaluator(object):
@@ -62,18 +64,19 @@ def test_reference_tree_behind_this_one(tmp_path):
         from clustercontrast.utils.data.device_pose import cords_to_map
         from clustercontrast.utils import to_numpy
         from clustercontrast.models.cm import ClusterMemory
-        from clustercontrast.evaluators import Evaluator, extract_features, pairwise_distance
+        from clustercontrast.evaluators import Evaluator, extract_features, extract_cnn_feature, pairwise_distance
         from reid.utils.data import Preprocessor, PoseMapGenerator
         from reid.utils import to_torch
         import reid.datasets
         REPO = %r
         assert clustercontrast.__version__ == 'ref-0.1' and datasets.NAMES == ['market1501']
         assert models.__file__.startswith(REPO) and sys.modules['clustercontrast.models.cm'].__file__.startswith(REPO)
-        assert extract_features.__module__ == 'clustercontrast.evaluators' and sys.modules['clustercontrast.evaluators'].__file__.startswith(REPO)
+        assert extract_cnn_feature.__module__ == 'clustercontrast.evaluators' and sys.modules['clustercontrast.evaluators'].__file__.startswith(REPO)
+        assert extract_features.__module__ == 'clustercontrast._ref_evaluators'       # the host loop is the reference's own
         assert Evaluator.__module__ == 'clustercontrast._ref_evaluators'
         # the reference's Evaluator now runs this build's functions
         import clustercontrast._ref_evaluators as R
-        assert R.extract_features is extract_features and R.pairwise_distance is pairwise_distance
+        assert R.extract_cnn_feature is extract_cnn_feature and R.pairwise_distance is pairwise_distance
         assert draw_pose_from_cords() == 'ref drawing helper' and to_numpy(0) == 'ref to_numpy' and to_torch(0) == 'ref to_torch'
         assert reid.models.__file__.startswith(REPO) and PoseMapGenerator.__module__ == 'reid.utils.data.device_pipeline'
         print('OVERLAY-OK')
@@ -85,7 +88,7 @@ def test_reference_tree_behind_this_one(tmp_path):
 
 
 def test_without_a_reference_tree_nothing_changes():
-    code = "import clustercontrast, reid, fdgan, dual_gan; from clustercontrast.evaluators import extract_features; print('OK')"
+    code = "import clustercontrast, reid, fdgan, dual_gan; from clustercontrast.evaluators import extract_cnn_feature, pairwise_distance; print('OK')"
     env = dict(os.environ)
     env["PYTHONPATH"] = os.path.join(REPO, "reid-gan_amd")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

@@ -1,0 +1,329 @@
+"""Paths of the drop-in API that no other GPU test executes (parity item 6c / 7): FD-GAN stage 1, label smoothing
+with a seeded `random`, the trainer LOOPS (`ClusterContrastTrainer.train`, `train_all`, `GANTrainer.train_gan`) with a
+3-iteration loader, `intra_cl`, checkpoint save -> load with `module.`-prefixed keys, the cascade evaluator's second stage,
+`--bipath_gan` / `--use_adp` construction, the optimizer state_dict round trip."""
+import argparse
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_torch as O
+from tests.test_modules_gpu import _check, _check_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _fd_opt(b, **kw):
+    d = dict(stage=2, checkpoints="/tmp/rg_paths", name="t", norm="batch", drop=0.0, connect_layers=0, fuse_mode="cat",
+             pose_feature_size=128, noise_feature_size=256, arch="resnet18", lr=0.001, niter=50, niter_decay=50,
+             lambda_recon=100.0, lambda_veri=10.0, lambda_sp=10.0, smooth_label=False, random_init=True, quiet=True, batch_size=b)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _fd_pair(dev, b, stage, smooth=False):
+    from fdgan.model import FDGANModel
+    torch.manual_seed(3)
+    # ResNet-18 trunks keep this CPU-oracle step to seconds; the 512-d feature feeds a generator built for it
+    oE = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True), O.OEltwiseSubEmbed(True, True, 2048, 2))
+    oDi = O.OSiameseNet(O.OReidResNet(50, cut_at_pooling=True), O.OEltwiseSubEmbed(True, True, 2048, 1))
+    oG = O.OPoseGenerator(128, 2048, 256, dropout=0.0)
+    oG.apply(O.o_weights_init_normal)
+    oDp = O.OPatchDiscriminator(21)
+    oDp.apply(O.o_weights_init_normal)
+    model = FDGANModel(_fd_opt(b, stage=stage, smooth_label=smooth, arch="resnet50"))
+    model.net_E.module.load_state_dict(oE.state_dict())
+    model.net_G.module.load_state_dict(oG.state_dict())
+    model.net_Di.module.load_state_dict(oDi.state_dict())
+    model.net_Dp.module.load_state_dict(oDp.state_dict())
+    model.reset_model_status()
+    ostep = O.OFDGANStep(oE, oG, oDi, oDp, lr=0.001, stage=stage, lambda_recon=100.0, lambda_veri=10.0, lambda_sp=10.0,
+                         smooth_label=smooth)
+    return model, ostep
+
+
+def _fd_feed(model, batch, b):
+    origin, target, pose, labels, noise = batch
+    pid1 = torch.arange(b)
+    pid2 = torch.where(labels == 1, pid1, pid1 + 1000)
+    model.set_input((dict(pid=pid1, origin=origin[:b], target=target[:b], posemap=pose[:b], noise=noise[:b]),
+                     dict(pid=pid2, origin=origin[b:], target=target[b:], posemap=pose[b:])))
+
+
+@pytest.mark.parametrize("stage,smooth", [(1, False), (2, True)])
+def test_fdgan_stage1_and_smooth_labels(dev, stage, smooth):
+    """stage 1 (E frozen and in eval mode, G + D_id + D_pd trained, D_id at lr * 0.01: FD/fdgan/model.py:72-79,100-107) and
+    smooth_label=True (GANLoss draws real / fake labels from `random`, label flip with p = 1/10001: :90-98,165-171) against
+    the oracle step with the SAME seeded `random` stream — the HIP model must consume the generator in the reference's order."""
+    b = 2
+    model, ostep = _fd_pair(dev, b, stage, smooth)
+    batch = O.synth_fdgan_batch(b, seed=9)
+    random.seed(1234)
+    ref, ref_fake = ostep.step(*batch)
+    state_after_oracle = random.getstate()
+    random.seed(1234)
+    _fd_feed(model, batch, b)
+    model.optimize_parameters()
+    assert random.getstate() == state_after_oracle, "the step consumed Python's random stream differently from the reference"
+    got = model.get_current_errors()
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 1e-3 * max(abs(v), 1e-3), (k, got[k], v)
+    _check(model.fake, ref_fake, 1e-3, "fake")
+    if stage == 1:
+        # E is not in any optimizer: its parameters are untouched by the step
+        for (n, p), (_, q) in zip(model.net_E.module.named_parameters(), ostep.net_E.named_parameters()):
+            assert torch.equal(p.detach().cpu(), q.detach()), n
+        assert not model.net_E.training
+
+
+class _Loader(object):
+    """IterLoader stand-in (CC/clustercontrast/utils/data/__init__.py:7-27): `.next()` and `len()`"""
+
+    def __init__(self, items):
+        self.items, self.i = items, 0
+
+    def __len__(self):
+        return len(self.items)
+
+    def next(self):
+        it = self.items[self.i % len(self.items)]
+        self.i += 1
+        return it
+
+
+def _cc_parts(dev, B, K=64):
+    from rg_hip import optim as roptim
+    import clustercontrast.models as M
+    from clustercontrast.models.cm import ClusterMemory
+    torch.manual_seed(0)
+    oenc = O.OCCResNet(18, pooling_type="gem")
+    enc = M.create('resnet18', pretrained=False, pooling_type="gem")
+    enc.load_state_dict(oenc.state_dict())
+    enc = enc.to(dev)
+    bank = F.normalize(torch.randn(K, enc.num_features), dim=1)
+    mem = ClusterMemory(enc.num_features, K, temp=0.05, momentum=0.1).to(dev)
+    mem.features = bank.clone().to(dev)
+    omem = O.OClusterMemory(enc.num_features, K, temp=0.05, momentum=0.1)
+    omem.features = bank.clone()
+    opt = roptim.Adam([{"params": [p]} for p in enc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    oopt = torch.optim.Adam([{"params": [p]} for p in oenc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    return enc, mem, opt, oenc, omem, oopt
+
+
+def test_cluster_contrast_trainer_train_loop(dev, capsys):
+    """`ClusterContrastTrainer.train` (CC/clustercontrast/trainers.py:219-263) end to end with a 3-iteration loader in the
+    dataloader's format (imgs, fnames, pids, cams, indexes): the loop, its parsing, the print line, three optimizer steps;
+    the per-iteration losses equal the oracle's `o_cc_step` sequence."""
+    from clustercontrast.trainers import ClusterContrastTrainer
+    B = 8
+    enc, mem, opt, oenc, omem, oopt = _cc_parts(dev, B)
+    g = torch.Generator().manual_seed(5)
+    items = []
+    for i in range(3):
+        imgs = torch.randn(B, 3, 64, 32, generator=g)
+        pids = torch.tensor([1, 1, 7, 7, 1, 9, 9, 7]) + i
+        items.append((imgs, ["f%d" % j for j in range(B)], pids, torch.zeros(B, dtype=torch.long), torch.arange(B)))
+    trainer = ClusterContrastTrainer(enc, mem)
+    trainer.sync_every_step = True
+    trainer.train(0, _Loader(items), opt, print_freq=1, train_iters=3)
+    out = capsys.readouterr().out
+    assert out.count("Epoch: [0][") == 3 and "Loss" in out
+    oenc.train()
+    ref = [O.o_cc_step(oenc, omem, oopt, it[0], it[2]) for it in items]
+    got = [float(x) for x in out.replace("(", " ").split("Loss")[1:]] if False else None
+    # the printed running value of the last iteration is the third loss
+    last = float(out.strip().splitlines()[-1].split("Loss")[1].split()[0])
+    assert abs(last - ref[2]) <= 2e-2 * abs(ref[2]) + 1e-3, (last, ref)
+    _check_l2(mem.features, omem.features, 2e-3, "bank after 3 steps")
+    assert enc.training
+
+
+def test_joint_trainer_train_all_and_gan_trainer_loops(dev, capsys):
+    """`ClusterContrastWithGANTrainer.train_all` (trainers.py:129-187 / trainers_b.py:617-814) and `GANTrainer.train_gan`
+    (:286-335) with 3-iteration loaders in the `[reid_batch, gan_dict]` format of Preprocessor._get_single_item_with_gan."""
+    from clustercontrast.trainers import ClusterContrastWithGANTrainer, GANTrainer
+    from dual_gan.models.models import create_model
+    from tests.test_dualgan_gpu import _gan_opt
+    from oracle import ref_dualgan as D
+    B = 4
+    enc, mem, opt, _, _, _ = _cc_parts(dev, B)
+    torch.manual_seed(1)
+    gan = create_model(_gan_opt(model="AE", num_feats=enc.num_features if False else 256))
+    gan_items, items = [], []
+    g = torch.Generator().manual_seed(6)
+    for i in range(3):
+        gi = D.synth_dualgan_inputs(B, 64, 32, seed=20 + i)
+        gi = {"Xs": gi["Xs"], "Ps": gi["Ps"], "Xs_path": ["a"] * B, "gt_label": torch.zeros(B)}
+        gan_items.append(gi)
+        reid = (torch.randn(B, 3, 64, 32, generator=g), ["f"] * B, torch.tensor([2, 2, 5, 5]), torch.zeros(B, dtype=torch.long),
+                torch.arange(B))
+        items.append([reid, gi])
+    trainer = ClusterContrastWithGANTrainer(enc, GAN=gan, memory=mem)
+    trainer.sync_every_step = True
+    # the encoder's feature map drives the 'Pose' generator: ResNet-18 gives 512 channels, the generator was built for 256
+    # -> use the ReID-only form of train_all (joint=False) for the loop mechanics, the joint step itself is covered by
+    # test_dualgan_gpu.py::test_joint_step_4a at matching widths
+    trainer.train_all(0, _Loader(items), opt, print_freq=1, train_iters=3, joint=False)
+    out = capsys.readouterr().out
+    assert "train both gan and reid" in out and out.count("Epoch: [0][") == 3
+    trainer.train(1, _Loader(items), opt, print_freq=3, train_iters=3)
+    assert capsys.readouterr().out.count("Epoch: [1][") == 1
+    # GAN-only warm-up loop on the auto-encoder generator (its forward takes the image alone)
+    torch.manual_seed(2)
+    gan2 = create_model(_gan_opt(model="AE", model_gen="AE"))
+    gt = GANTrainer(gan2, enc, None, None)
+    gt.train_gan(0, _Loader(gan_items), print_freq=1, train_iters=3)
+    out = capsys.readouterr().out
+    assert "train gan" in out and out.count("GANLoss: G:") == 3
+    errs = gan2.get_current_errors()
+    assert np.isfinite(errs["G"]) and np.isfinite(errs["D"])
+    gan2.update_learning_rate()
+    lr_g, lr_d = gan2.get_current_learning_rate()
+    assert lr_g > 0 and abs(lr_d - 0.1 * lr_g) < 1e-12
+
+
+def test_intra_cl_matches_reference_formula(dev):
+    """group contrast of trainers.py:200-210 against its torch restatement"""
+    from clustercontrast.trainers import ClusterContrastWithGANTrainer
+    tr = ClusterContrastWithGANTrainer(encoder=torch.nn.Identity(), GAN=object(), memory=None,
+                                       opt=argparse.Namespace(cl_temp=0.07))
+    g = torch.Generator().manual_seed(8)
+    gs = 4
+    q, k = torch.randn(gs * gs, 32, generator=g), torch.randn(gs * gs, 32, generator=g)
+    qd, kd = q.to(dev).requires_grad_(True), k.to(dev).requires_grad_(True)
+    loss = tr.intra_cl(qd, kd, group_size=gs)
+    loss.mean().backward()
+    qr, kr = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    logits = F.normalize(qr, dim=1).mm(F.normalize(kr, dim=1).t())
+    logits = logits.reshape(gs * gs, -1, gs).sum(-1) / 0.07
+    targets = torch.arange(gs, dtype=torch.long).repeat_interleave(gs)
+    ref = F.cross_entropy(logits, targets, reduction="none")
+    ref.mean().backward()
+    _check(loss, ref, 1e-4, "intra_cl loss")
+    _check(qd.grad, qr.grad, 1e-3, "intra_cl dq")
+    _check(kd.grad, kr.grad, 1e-3, "intra_cl dk")
+
+
+def test_checkpoint_roundtrip_with_module_prefix(dev, tmp_path):
+    """FDGANModel.save -> files `{epoch}_net_{E,G,Di,Dp}.pth` whose keys carry the DataParallel `module.` prefix
+    (FD/fdgan/model.py:250-259); a second model loads them through `remove_module_key` (networks.py:51-55) and through
+    the netX_pretrain options of stage 2; a reference-format file (bare torch tensors, `module.` keys) loads as well."""
+    from fdgan.model import FDGANModel
+    from fdgan.networks import remove_module_key
+    torch.manual_seed(11)
+    m1 = FDGANModel(_fd_opt(2, checkpoints=str(tmp_path), name="ck"))
+    m1.save(7)
+    files = sorted(os.listdir(os.path.join(str(tmp_path), "ck")))
+    assert files == ["7_net_Di.pth", "7_net_Dp.pth", "7_net_E.pth", "7_net_G.pth"]
+    sd = torch.load(os.path.join(str(tmp_path), "ck", "7_net_E.pth"))
+    assert all(k.startswith("module.") for k in sd) and "module.base_model.base.conv1.weight" in sd
+    assert "module.embed_model.bn.running_mean" in sd and not any(v.is_cuda for v in sd.values())
+    paths = {n: os.path.join(str(tmp_path), "ck", "7_net_%s.pth" % n) for n in ("E", "G", "Di", "Dp")}
+    torch.manual_seed(12)
+    m2 = FDGANModel(_fd_opt(2, random_init=False, netE_pretrain=paths["E"], netG_pretrain=paths["G"],
+                            netDi_pretrain=paths["Di"], netDp_pretrain=paths["Dp"]))
+    for n in ("E", "G", "Di", "Dp"):
+        a, b = getattr(m1, "net_" + n).state_dict(), getattr(m2, "net_" + n).state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert torch.equal(a[k].cpu(), b[k].cpu()), (n, k)
+    stripped = remove_module_key(sd)
+    assert "base_model.base.conv1.weight" in stripped
+    # parameters are still views of the optimizer arenas after loading
+    p = next(m2.net_G.parameters())
+    assert p.data_ptr() == m2.optimizer_G._arena.flat[p._rg_offset:].data_ptr()
+    m2.update_learning_rate()
+
+
+def test_optimizer_state_dict_roundtrip(dev):
+    from rg_hip import optim as roptim
+    torch.manual_seed(0)
+    net = torch.nn.Linear(6, 5).to(dev)
+    ref = torch.nn.Linear(6, 5)
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    opt, ropt = roptim.Adam(net.parameters(), lr=1e-2, betas=(0.5, 0.999)), torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    x = torch.randn(4, 6)
+    for _ in range(2):
+        opt.zero_grad()
+        net(x.to(dev)).pow(2).sum().backward()
+        opt.step()
+        ropt.zero_grad()
+        ref(x).pow(2).sum().backward()
+        ropt.step()
+    sd, rsd = opt.state_dict(), ropt.state_dict()
+    assert sorted(sd["state"]) == sorted(rsd["state"]) and float(sd["state"][0]["step"]) == 2.0
+    for i in rsd["state"]:
+        _check(sd["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"], 1e-5, "exp_avg")
+        _check(sd["state"][i]["exp_avg_sq"], rsd["state"][i]["exp_avg_sq"], 1e-5, "exp_avg_sq")
+    net2 = torch.nn.Linear(6, 5).to(dev)
+    net2.load_state_dict(net.state_dict())
+    opt2 = roptim.Adam(net2.parameters(), lr=1.0)
+    opt2.load_state_dict(sd)
+    for o, n_ in ((opt, net), (opt2, net2)):
+        o.zero_grad()
+        n_(x.to(dev)).pow(2).sum().backward()
+        o.step()
+    assert torch.equal(net.weight, net2.weight)          # the resumed optimizer continues bit-identically
+
+
+def test_cascade_evaluator_second_stage(dev):
+    """CascadeEvaluator second stage (FD/reid/evaluators.py:198-227) on synthetic features: device top-k + one batched
+    embedding-network pass against the per-query loop of the reference (oracle.o_cascade_second_stage)."""
+    from reid.evaluators import CascadeEvaluator, pairwise_distance
+    from reid.models.embedding import EltwiseSubEmbed
+    torch.manual_seed(4)
+    Q, G, D, k = 7, 40, 64, 6
+    probe, gal = torch.randn(Q, D), torch.randn(G, D)
+    oemb = O.OEltwiseSubEmbed(True, True, D, 2)
+    with torch.no_grad():
+        oemb.classifier.weight.normal_(0, 0.05)
+        oemb.bn.running_mean.normal_(0, 0.1)
+        oemb.bn.running_var.uniform_(0.5, 1.5)
+    emb = EltwiseSubEmbed(use_batch_norm=True, use_classifier=True, num_features=D, num_classes=2)
+    emb.load_state_dict(oemb.state_dict())
+    emb.to(dev)
+    query = [("q%d" % i, i, 0) for i in range(Q)]
+    gallery = [("g%d" % j, j, 1) for j in range(G)]
+    features = {"q%d" % i: probe[i] for i in range(Q)}
+    features.update({"g%d" % j: gal[j] for j in range(G)})
+    dist_fn = lambda x: F.softmax(x, dim=1)[:, 0]        # baseline.py:102 embed_dist_fn
+    d1 = pairwise_distance(features, query, gallery)
+    _check(d1, O.o_pairwise_distance(probe, gal), 1e-4, "first stage distances")
+    ev = CascadeEvaluator(None, emb, dist_fn)
+    merged = ev.second_stage(d1, features, query, gallery, rerank_topk=k)
+    ref = O.o_cascade_second_stage(O.o_pairwise_distance(probe, gal), probe, gal, oemb, k, dist_fn)
+    assert np.abs(merged - ref).max() <= 1e-4 * np.abs(ref).max(), np.abs(merged - ref).max()
+    # the ranking the metrics see is identical
+    assert (np.argsort(merged, axis=1, kind="stable") == np.argsort(ref, axis=1, kind="stable")).all()
+
+
+def test_bipath_and_adaptor_construction(dev):
+    """--bipath_gan builds net_Gb / net_Db and puts them into the optimizers as second parameter groups, --use_adp builds
+    net_A (AE_model.py:78-107,130-156); nothing in the reference ever calls them."""
+    from dual_gan.models.models import create_model
+    from dual_gan.models import networks
+    from tests.test_dualgan_gpu import _gan_opt
+    torch.manual_seed(0)
+    gan = create_model(_gan_opt(model="AE", bipath_gan=True, use_adp=True))
+    assert gan.model_names == ['G', 'Gb', 'A', 'D', 'Db']
+    assert len(gan.optimizer_G.param_groups) == 2 and len(gan.optimizer_D.param_groups) == 2
+    n_g = sum(p.numel() for p in gan.net_G.parameters())
+    assert sum(p.numel() for g in gan.optimizer_G.param_groups for p in g["params"]) == n_g + sum(p.numel() for p in gan.net_Gb.parameters())
+    assert isinstance(gan.net_A, networks.Resize_ReID)
+    keys = list(gan.net_A.state_dict())
+    assert "resblock1.conv1.weight_orig" in keys and "resblock3.bypass.weight_u" in keys
+    # the adaptor is a working module: 128x64 -> 256x128 with gradients
+    x = torch.rand(2, 3, 128, 64, device=dev).requires_grad_(True)
+    y = gan.net_A(x)
+    assert tuple(y.shape) == (2, 3, 256, 128)
+    y.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    import tempfile
+    gan.save_dir = tempfile.mkdtemp()
+    gan.save_networks("latest")
+    assert sorted(os.listdir(gan.save_dir)) == ["latest_net_A.pth", "latest_net_D.pth", "latest_net_Db.pth",
+                                                "latest_net_G.pth", "latest_net_Gb.pth"]
