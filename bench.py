@@ -389,15 +389,15 @@ def pmc_traffic(key, launches_per_step):
                 doc = json.load(f)
         except (OSError, ValueError):
             continue
-        fam = doc.get("configs", {}).get(key, {}).get("families", {}).get("conv")
+        fam = doc.get("configs", {}).get(key, {}).get("families", {}).get("conv_f8" if key == "5" else "conv")
         if fam is None and key == "2":
             fam = doc.get("families", {}).get("conv")
         if fam is None:
             continue
         per_step = fam["read_bytes_per_step"] + fam["write_bytes_per_step"]
         return round(per_step / max(launches_per_step, 1)), (
-            "profiles/%s: %.1f GB read + %.1f GB written per step by the conv family incl. split-K finish/reduce and filter "
-            "re-layout kernels" % (name, fam["read_bytes_per_step"] / 1e9, fam["write_bytes_per_step"] / 1e9))
+            "profiles/%s: %.1f GB read + %.1f GB written per step by the conv family incl. split-K finish/reduce, filter "
+            "re-layout and (fp8) quantisation kernels" % (name, fam["read_bytes_per_step"] / 1e9, fam["write_bytes_per_step"] / 1e9))
     return None, "no PMC pass committed for this configuration"
 
 
@@ -417,10 +417,27 @@ def measure(w, args, dev, rank, world, use_dist, headline):
         if rank == 0 and headline:
             torch.cuda.synchronize()
             log("warm-up step %d done" % i)
+    run = w.step
+    graphed = False
+    if args.graph == "on" or (args.graph == "auto" and not use_dist):
+        # the whole step as ONE hipGraph launch (rg_hip/graph.py): captured after the warm-up steps, two replays before the
+        # timed region.  Multi-GPU runs stay eager (RCCL collectives inside a captured step are not validated on this stack).
+        from rg_hip.graph import CapturedStep
+        try:
+            cs = CapturedStep(w.step, warmup=0)
+            cs()
+            cs()
+            torch.cuda.synchronize()
+            run, graphed = cs, True
+        except Exception as e:                                  # fall back to eager launches and say so in the JSON line
+            if args.graph == "on":
+                raise
+            log("config %s: step capture failed (%s: %s); eager launches" % (w.key, type(e).__name__, str(e)[:200]))
+            torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        w.step()
+        run()
     t_host = time.perf_counter() - t0                       # host enqueue time: no synchronisation inside the loop
     barrier()
     elapsed = time.perf_counter() - t0
@@ -481,6 +498,7 @@ def measure(w, args, dev, rank, world, use_dist, headline):
     ms_step = 1e3 * elapsed / steps
     return {"value": round(world * w.crops * steps / elapsed, 2), "ms_per_step": round(ms_step, 3), "steps": steps,
             "warmup": warmup, "host_enqueue_ms_per_step": round(1e3 * t_host / steps, 3),
+            "launch": "hipGraph replay of the captured step" if graphed else "eager (one hipLaunchKernel per kernel from Python)",
             "losses": {k: round(float(v), 5) for k, v in losses.items()}, "roofline": roof,
             "step_tflops_algorithmic": round(w.gflop_per_crop * w.crops / 1e3 / (ms_step * 1e-3), 2)}
 
@@ -515,6 +533,10 @@ def main():
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each configuration under other_configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="measure only --config")
+    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                    help="replay the step as one captured hipGraph (rg_hip/graph.py).  Off by default: measured on ROCm 7.2 the "
+                         "replay of these 1 000+ node multi-stream graphs costs the host as much as the eager launches "
+                         "(profiles/r02_graph_vs_eager.txt)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -582,7 +604,7 @@ def main():
             "config": {"workload": w.describe, "baseline_config": w.key, "crops_per_gpu": w.crops,
                        "global_batch_crops": world * w.crops, "parallelism": "dp%d" % world},
             "step_tflops_algorithmic": head["step_tflops_algorithmic"],
-            "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+            "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"], "launch": head["launch"],
             "losses": head["losses"],
             "roofline": head["roofline"], "cpu_baseline": cpu,
         }

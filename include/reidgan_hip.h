@@ -63,16 +63,11 @@ size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q
  * kernels walk the reduction (r,s)-major, so the padding test of the pixel gather happens once per 16-deep k-tile
  * (fwd, C % 16 == 0) and the weight operand of the data gradient is contiguous (float4 loads; K % 16 == 0,
  * C % 4 == 0); NULL selects the generic loaders.  Workspace: split-K scratch for layers too small to fill the chip
- * (dgrad: stride 1 only); a too-small workspace just disables the split.  tile_counters (may be NULL): RG_TILE_COUNTERS
- * ints of device memory, all zero on entry and all zero again when the launch has finished; with them the partial tiles of a
- * split reduction are summed inside the launch by the last workgroup to arrive at each output tile (agent-scope release /
- * acquire) instead of by a finishing launch.  The buffer must not be shared by launches that can run concurrently (one per
- * stream).  Every tensor must be < 2 GiB. */
-#define RG_TILE_COUNTERS 16384
+ * (dgrad: stride 1 only); a too-small workspace just disables the split.  Every tensor must be < 2 GiB. */
 int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y, int N, int C, int H, int W, int K,
                   int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift,
                   const float* residual, int act, float slope, void* workspace, size_t workspace_bytes,
-                  int* tile_counters, rg_stream_t stream);
+                  rg_stream_t stream);
 size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW);
 /* relu_mask (dgrad only, may be NULL): a tensor shaped like dx; after scale/shift/residual/act the result is zeroed where
  * relu_mask <= 0.  Passing the convolution's own forward INPUT (the ReLU output of the layer below) makes this the
@@ -80,7 +75,7 @@ size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int 
 int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K,
                     int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
                     const float* shift, const float* residual, int act, float slope, const float* relu_mask,
-                    float* rowsum, int rowsum_cols, void* workspace, size_t workspace_bytes, int* tile_counters, rg_stream_t stream);
+                    float* rowsum, int rowsum_cols, void* workspace, size_t workspace_bytes, rg_stream_t stream);
 /* rowsum (dgrad only, may be NULL): [C][rowsum_cols] — per input channel, the sums of the FINAL dx values over blocks of
  * pixels (one column per class, pixel tile and wave column; fixed summation order).  Their sum over the columns is the
  * per-channel sum of dx: exactly the `partials` rg_bn_fold_wgrad of the layer below needs (dbeta / dgamma), so that layer does
@@ -96,14 +91,6 @@ size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,
                     rg_stream_t stream);
-/* the same for a convolution whose frozen-statistics BatchNorm is folded into it (FD-GAN's E and D_id, `set_bn_fix`,
- * FD/fdgan/networks.py:57-60): dw = scale[k] * G with G = wgrad(x, g); dgamma[k] = invstd[k] * (sum w.G - mean[k] * sum_g[k]);
- * sum_g directly or as n_slices partials per channel (then dbeta[k] = their sum is written too) */
-int rg_conv2d_wgrad_bnfold(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
-                           int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,
-                           const float* w, const float* scale, const float* invstd, const float* running_mean,
-                           const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma,
-                           rg_stream_t stream);
 
 /* ---- BatchNorm 1d/2d on [N][C][HW] ------------------------------------------------------------
  * Replaces nn.BatchNorm2d/1d (FD/fdgan/networks.py:26-35; resnet_ibn_a.py:75-81; FD/reid/models/
@@ -140,6 +127,8 @@ int rg_sub_square_bwd(const float* a, const float* b, const float* dy, float* da
                       rg_stream_t stream);
 /* nn.Dropout of the generator decoder, FD/fdgan/networks.py:105-109,149-156; counter-based mask */
 int rg_dropout(const float* x, float* y, int64_t n, float p, unsigned long long seed, rg_stream_t stream);
+int rg_dropout_clocked(const float* x, float* y, int64_t n, float p, unsigned long long seed, const unsigned long long* clock,
+                       rg_stream_t stream);
 /* F.normalize(x, dim=1) on [rows][D], CC/clustercontrast/models/cm.py:125, resnet.py:90-107 */
 int rg_l2norm_rows_fwd(const float* x, float* y, float* norm, int rows, int D, float eps, rg_stream_t stream);
 int rg_l2norm_rows_bwd(const float* y, const float* dy, const float* norm, float* dx, int rows, int D, float eps,
@@ -339,6 +328,13 @@ int rg_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, in
                  float beta2, float eps, float weight_decay, int step, float grad_scale, rg_stream_t stream);
 int rg_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                 float weight_decay, int first_step, float grad_scale, rg_stream_t stream);
+/* Device-side clocks for hipGraph replay (kernel arguments are frozen at capture, so per-step values live in device memory):
+ * Adam state double[4] = {step, beta1^step, beta2^step, -} (initialise {0, 1, 1, 0}); rg_adam_advance once per optimizer step,
+ * then rg_adam_step_dev per parameter range; rg_u64_add advances a step counter that rg_dropout_clocked mixes into its seed. */
+int rg_adam_advance(double* state, float beta1, float beta2, rg_stream_t stream);
+int rg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, const double* state, float grad_scale, rg_stream_t stream);
+int rg_u64_add(unsigned long long* p, unsigned long long v, rg_stream_t stream);
 
 /* ---- on-device input synthesis: the reference's per-sample PIL / scipy steps as batch kernels ---- */
 /* Pose heat maps out[N][J][H][W] from integer joint centres centers[N][J][2] = (row, col); a negative (or out-of-range)

@@ -95,7 +95,6 @@ struct ConvP {
     // split-K (fwd / dgrad: partial tiles to `partial`; wgrad: to y)
     int ktiles_per_split, splits;
     float* partial;
-    int* counters;    // fwd / dgrad split-K: one arrival counter per output tile (zero before and after every launch) or null
     // buffer-resource sizes (bytes, < 2^31) of x / w / y / partial, and extra dividers for the (r,s)-major orders
     unsigned x_bytes, w_bytes, y_bytes, partial_bytes;
     FastDiv d_c, d_k;
@@ -113,7 +112,6 @@ struct DgradP {
 
 template <int BM, int BN, int WM, int WN>
 struct Tile {
-    static constexpr int BM_ = BM, BN_ = BN;
     static constexpr int LDA = BM + LPAD;
     static constexpr int LDB = BN + LPAD;
     static constexpr int WTM = BM / WM;
@@ -318,165 +316,27 @@ __device__ __forceinline__ void store_tile_epilogue_any(const ConvP& p, const fl
 // Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
 // With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] instead.  Buffer stores: one VALU add per
 // element, lanes outside the tensor carry OOB and are dropped by the hardware.
-// Split-K without a finishing launch: every workgroup of a tile writes its partial accumulators as a slab in FRAGMENT order
-// (element e of thread t at slab + (e * 256 + t) * 4: fully coalesced, one base register + a constant scalar offset per
-// access, no index arithmetic), publishes it (each storing wave drains its stores, the workgroup meets at a barrier, one lane
-// issues an agent-scope release and takes a ticket from the tile's arrival counter); the workgroup that draws the last ticket
-// acquires (agent scope: its CU's L1 is invalidated, the producers' L2 lines were written back by their releases), re-reads
-// ALL slabs in split order — so the sum does not depend on the arrival order — and runs the ordinary fused epilogue.  It also
-// resets the counter, so the buffer is all zero again when the launch ends (cdna_hip_programming.md, "In-launch split-K
-// reduction").  Returns true when this workgroup holds the complete sums in `acc` and has to write the output.
 template <typename T>
-__device__ __forceinline__ bool splitk_arrive_and_reduce(const ConvP& p, floatx16 (&acc)[T::TM][T::TN], int tile_id, int n_tiles_all,
-                                                         int split) {
-    __shared__ int s_last;
-    constexpr unsigned SLAB = (unsigned)T::BM_ * T::BN_ * 4u;
-    const rsrc_t rp = make_rsrc(p.partial, p.partial_bytes);
-    {
-        const unsigned base = (unsigned)(split * n_tiles_all + tile_id) * SLAB + threadIdx.x * 4u;
-#pragma unroll
-        for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < T::TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[i][j][r]), rp, base,
-                                                          ((i * T::TN + j) * 16 + r) * 1024, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == p.splits - 1;
-        if (last) {
-            __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return false;
-    zero_acc<T>(acc);
-#pragma unroll 1
-    for (int sp = 0; sp < p.splits; ++sp) {
-        const unsigned base = (unsigned)(sp * n_tiles_all + tile_id) * SLAB + threadIdx.x * 4u;
-#pragma unroll
-        for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < T::TN; ++j) {
-                float v[16];            // 16 loads in flight per batch: bounds the live registers next to the accumulators
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, base, ((i * T::TN + j) * 16 + r) * 1024, 0));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    }
-    return true;
-}
-
-// Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
-// With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] instead.  Buffer stores: one VALU add per
-// element, lanes outside the tensor carry OOB and are dropped by the hardware.
-// Split-K without a finishing launch: every workgroup of a tile writes its partial slab, publishes it (each storing wave
-// drains its stores, the workgroup meets at a barrier, one lane issues an agent-scope release and takes a ticket from the
-// tile's arrival counter); the workgroup that draws the last ticket acquires (agent scope: its CU's L1 is invalidated, the
-// producers' L2 lines were written back by their releases), re-reads ALL slabs in split order — so the sum does not depend on
-// the arrival order and equals the finishing kernel's — and runs the ordinary fused epilogue.  It also resets the counter, so
-// the buffer is all zero again when the launch ends (cdna_hip_programming.md, "In-launch split-K reduction").
-// Returns true when this workgroup holds the complete sums in `acc` and has to write the output.
-template <typename T>
-__device__ __forceinline__ bool splitk_arrive_and_reduce(const ConvP& p, floatx16 (&acc)[T::TM][T::TN], int tile_id, int mrow0,
-                                                         const unsigned (&pb)[T::TN], unsigned rstride, unsigned slab_bytes) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == p.splits - 1;
-        if (last) {
-            __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return false;
-    const rsrc_t rp = make_rsrc(p.partial, p.partial_bytes);
-    zero_acc<T>(acc);
-#pragma unroll 1
-    for (int sp = 0; sp < p.splits; ++sp) {
-        const unsigned so = (unsigned)sp * slab_bytes;
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j)
-#pragma unroll
-            for (int i = 0; i < T::TM; ++i) {
-                // 16 loads in flight per batch: bounds the live registers next to the 16 * TM * TN accumulators
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
-                    const unsigned off = (pb[j] != OOB && mrow0 + mo < p.M) ? pb[j] + so + (unsigned)mo * rstride : OOB;
-                    v[r] = bload(rp, off);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    }
-    return true;
-}
-
-// Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
-// With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] first (see splitk_arrive_and_reduce; without
-// counters a finishing kernel sums them).  Buffer stores: one VALU add per element, lanes outside the tensor carry OOB and
-// are dropped by the hardware.
-template <typename T, bool SPLITK>
-__device__ __forceinline__ void store_tile_nchw(const ConvP& p, floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
+__device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0,
                                                 int wm, int wn, int lane, int Ng, int PIX, const FastDiv& d_pix,
-                                                int split, int pcol = 0, int tile_id = 0) {
+                                                int split, int pcol = 0) {
     const int l32 = lane & 31, kh = lane >> 5;
     const int mrow0 = m0 + wm * T::WTM + 4 * kh;
-    if constexpr (SPLITK) {
-        if (p.counters) {
-            if (!splitk_arrive_and_reduce<T>(p, acc, tile_id, (int)gridDim.x, split)) return;
-        } else {                                          // no counters given: [split][M][Ng] partials + finishing kernel
-            const rsrc_t ro = make_rsrc(p.partial, p.partial_bytes);
-            const unsigned rstride = (unsigned)Ng * 4u;
-#pragma unroll
-            for (int j = 0; j < T::TN; ++j) {
-                const int nn = n0 + wn * T::WTN + j * 32 + l32;
-                const unsigned ob = nn < Ng ? (unsigned)(((split * p.M + mrow0) * (int64_t)Ng + nn) * 4) : OOB;
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
-                        const unsigned off = (mrow0 + mo < p.M) ? ob + (unsigned)mo * rstride : OOB;
-                        bstore(ro, off, acc[i][j][r]);
-                    }
-            }
-            return;
-        }
-    }
     const bool plain = !p.ep.scale && !p.ep.shift && !p.ep.res && !p.ep.mask && !p.ep.rowsum && p.ep.act == RG_ACT_NONE;
-    if (plain) {
-        const rsrc_t ro = make_rsrc(p.y, p.y_bytes);
-        const unsigned rstride = (unsigned)PIX * 4u;    // bytes between GEMM rows
+    if (p.partial || plain) {
+        const rsrc_t ro = p.partial ? make_rsrc(p.partial, p.partial_bytes) : make_rsrc(p.y, p.y_bytes);
+        const unsigned rstride = (p.partial ? (unsigned)Ng : (unsigned)PIX) * 4u;    // bytes between GEMM rows
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) {
             const int nn = n0 + wn * T::WTN + j * 32 + l32;
             unsigned ob = OOB;
             if (nn < Ng) {
-                const int im = fdiv(nn, d_pix);
-                ob = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+                if (p.partial) {
+                    ob = (unsigned)(((split * p.M + mrow0) * (int64_t)Ng + nn) * 4);
+                } else {
+                    const int im = fdiv(nn, d_pix);
+                    ob = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+                }
             }
 #pragma unroll
             for (int i = 0; i < T::TM; ++i)
@@ -525,7 +385,7 @@ struct ALoadK {
 //           BMODE 1: (r, s)-major order k' = rs*C + c, weights [K][KH*KW][C], C % 16 == 0: one bounds test per tile
 //           BMODE 2: 1x1 / stride 1 / pad 0 with H*W % 4 == 0: pixel operand as float4
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC, bool SPLITK>
+template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) void conv_fwd_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
@@ -537,7 +397,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int split = SPLITK ? (int)blockIdx.y : 0;
+    const int split = blockIdx.y;
     const int HW = p.H * p.W;
     const int RS = p.KH * p.KW;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -662,8 +522,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     };
 
     const int nk = (p.Kg + BK - 1) / BK;
-    const int kt_begin = SPLITK ? split * p.ktiles_per_split : 0;
-    int kt_end = SPLITK ? kt_begin + p.ktiles_per_split : nk;
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
     if (kt_end > nk) kt_end = nk;
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
@@ -680,7 +540,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
         __syncthreads();
         cur ^= 1;
     }
-    store_tile_nchw<T, SPLITK>(p, acc, m0, n0, wm, wn, lane, p.Ng, p.P * p.Q, p.d_pq, split, 0, tile);
+    store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, p.Ng, p.P * p.Q, p.d_pq, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -690,7 +550,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
 //         C % 4 == 0: weight operand float4 along C, one bounds test per tile for dy
 // MODE 2: MODE 1 layout + 1x1 / stride 1 / pad 0 with P*Q % 4 == 0: dy loads as float4 too (any K)
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool SPLITK>
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) void conv_dgrad_kernel(const DgradP dp) {
     using T = Tile<BM, BN, WM, WN>;
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
@@ -708,7 +568,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int split = SPLITK ? (int)blockIdx.y : 0;
+    const int split = blockIdx.y;
     const int PQ = p.P * p.Q;
     const int RS = p.KH * p.KW;
     const int taps = cl.nrh * cl.nrw;
@@ -853,8 +713,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     };
 
     const int nk = (cl.Kgc + BK - 1) / BK;
-    const int kt_begin = SPLITK ? split * p.ktiles_per_split : 0;
-    int kt_end = SPLITK ? kt_begin + p.ktiles_per_split : nk;
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
     if (kt_end > nk) kt_end = nk;
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
@@ -873,7 +733,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     }
 
     if (p.SH == 1 && p.SW == 1) {       // one class: output pixels are contiguous, shared epilogue (+ split-K)
-        store_tile_nchw<T, SPLITK>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * WN + wn, tile);
+        store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * WN + wn);
         return;
     }
     // strided classes: pixel (hc, wc) of the class lands on (ah + SH*hc, aw + SW*wc); same fused epilogue
@@ -1460,68 +1320,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // algorithmic HBM bytes of one conv launch: one read of each operand + one write of the result (fp32)
 #define ALG_BYTES (4.0 * ((double)N * C * H * W + (double)K * C * KH * KW + (double)N * K * P * Q))
 
-// Split-K sum of the weight gradient of a (conv, frozen-statistics BatchNorm) pair together with the pair's finishing pass
-// (what bn_fold_wgrad_kernel did in a launch of its own, csrc/norm.hip): one workgroup per filter k,
-//   G[m]      = sum_s ws[s][k][m]                 64 columns x 4 split lanes per pass, fixed summation tree: deterministic
-//   dw[k][m]  = scale[k] * G[m]
-//   dgamma[k] = invstd[k] * (sum_m w[k][m] G[m] - mean[k] * sum_g[k]),   sum_g[k] = sum of the slice partials (-> dbeta[k])
-struct BnFold {
-    const float* w;
-    const float* scale;
-    const float* invstd;
-    const float* mean;
-    const float* sum_g;
-    const float* part;
-    int S;
-    float* dbeta;
-    float* dgamma;
-};
-
-__global__ __launch_bounds__(256) void splitk_reduce_bnfold_kernel(const float* __restrict__ ws, float* __restrict__ out, int M,
-                                                                   int64_t slab, int splits, BnFold bf) {
-    __shared__ float red4[4][64];
-    __shared__ float red[16];
-    const int k = blockIdx.x;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    float sg = 0.f;
-    if (bf.part) {
-        float t = 0.f;
-        for (int s = threadIdx.x; s < bf.S; s += 256) t += bf.part[(int64_t)k * bf.S + s];
-        sg = rg_block_sum(t, red);
-        if (bf.dbeta && threadIdx.x == 0) bf.dbeta[k] = sg;
-    } else if (bf.sum_g) {
-        sg = bf.sum_g[k];
-    }
-    const float sc = bf.scale[k];
-    const float* wr = bf.w + (int64_t)k * M;
-    float dot = 0.f;
-    for (int m0 = 0; m0 < M; m0 += 64) {
-        const int m = m0 + tx;
-        float s0 = 0.f, s1 = 0.f;
-        if (m < M) {
-            const float* src = ws + (int64_t)k * M + m;
-            int sp = ty;
-            for (; sp + 4 < splits; sp += 8) {
-                s0 += src[(int64_t)sp * slab];
-                s1 += src[(int64_t)(sp + 4) * slab];
-            }
-            if (sp < splits) s0 += src[(int64_t)sp * slab];
-        }
-        __syncthreads();
-        red4[ty][tx] = s0 + s1;
-        __syncthreads();
-        if (ty == 0 && m < M) {
-            const float G = (red4[0][tx] + red4[1][tx]) + (red4[2][tx] + red4[3][tx]);
-            dot += wr[m] * G;
-            out[(int64_t)k * M + m] = sc * G;
-        }
-    }
-    if (bf.dgamma) {
-        dot = rg_block_sum(dot, red);
-        if (threadIdx.x == 0) bf.dgamma[k] = bf.invstd[k] * (dot - bf.mean[k] * sg);
-    }
-}
-
 static bool fits_buffer(int64_t elems) { return elems > 0 && elems * 4 < (1ll << 31); }
 
 static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW,
@@ -1536,7 +1334,6 @@ static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int
     p.ktiles_per_split = 1 << 30;
     p.splits = 1;
     p.partial = nullptr;
-    p.counters = nullptr;
     p.x_bytes = p.w_bytes = p.y_bytes = p.partial_bytes = 0;
     p.d_c = make_fastdiv(C);
     p.d_k = make_fastdiv(K);
@@ -1631,18 +1428,6 @@ static GemmPlan plan_gemm(int M, int64_t Ng, int64_t Kg, bool allow_split) {
     return pl;
 }
 
-// in-kernel split-K reduction (see splitk_arrive_and_reduce); RG_SPLITK_FUSED=0 restores the finishing launch
-constexpr int RG_TILE_COUNTERS = 16384;
-static bool fused_splitk() {
-    static const int env = getenv("RG_SPLITK_FUSED") ? atoi(getenv("RG_SPLITK_FUSED")) : 1;
-    return env != 0;
-}
-
-// bytes of the fragment-order slabs of the in-kernel reduction: splits x tiles x (BM x BN) floats
-static size_t fused_slab_bytes(const GemmPlan& pl, int64_t n_tiles) {
-    return (size_t)pl.splits * (size_t)pl.m_tiles * (size_t)n_tiles * (size_t)kTileBM[pl.tile] * kTileBN[pl.tile] * sizeof(float);
-}
-
 static unsigned finish_grid(int64_t n) {
     int64_t g = rg::cdiv64(n, 256);
     if (g > 4096) g = 4096;
@@ -1651,23 +1436,16 @@ static unsigned finish_grid(int64_t n) {
 
 }  // namespace
 
-#define RG_FWD_LAUNCH_S(BM_, BN_, WM_, WN_, S_)                                                                           \
-    if (bmode == 2) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 2, true, S_>), grid, dim3(NT), 0, stream, p); \
-    else if (bmode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, true, S_>), grid, dim3(NT), 0, stream, p); \
-    else if (avec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, true, S_>), grid, dim3(NT), 0, stream, p);  \
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, false, S_>), grid, dim3(NT), 0, stream, p)
-// split-K launches run the instantiation that carries the partial-tile / in-kernel reduction path; all others the lean one
-#define RG_FWD_LAUNCH(BM_, BN_, WM_, WN_)                         \
-    if (p.partial) { RG_FWD_LAUNCH_S(BM_, BN_, WM_, WN_, true); } \
-    else { RG_FWD_LAUNCH_S(BM_, BN_, WM_, WN_, false); }
+#define RG_FWD_LAUNCH(BM_, BN_, WM_, WN_)                                                                             \
+    if (bmode == 2) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 2, true>), grid, dim3(NT), 0, stream, p); \
+    else if (bmode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, true>), grid, dim3(NT), 0, stream, p); \
+    else if (avec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, true>), grid, dim3(NT), 0, stream, p);  \
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 0, false>), grid, dim3(NT), 0, stream, p)
 
-#define RG_DGRAD_LAUNCH_S(BM_, BN_, WM_, WN_, S_)                                                                        \
-    if (mode == 2) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 2, S_>), grid, dim3(NT), 0, stream, dp);    \
-    else if (mode == 1) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1, S_>), grid, dim3(NT), 0, stream, dp); \
-    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 0, S_>), grid, dim3(NT), 0, stream, dp)
-#define RG_DGRAD_LAUNCH(BM_, BN_, WM_, WN_)                         \
-    if (p.partial) { RG_DGRAD_LAUNCH_S(BM_, BN_, WM_, WN_, true); } \
-    else { RG_DGRAD_LAUNCH_S(BM_, BN_, WM_, WN_, false); }
+#define RG_DGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                          \
+    if (mode == 2) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(NT), 0, stream, dp);    \
+    else if (mode == 1) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(NT), 0, stream, dp); \
+    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(NT), 0, stream, dp)
 
 #define RG_TILE_SWITCH(tile, LAUNCH)      \
     switch (tile) {                       \
@@ -1714,10 +1492,7 @@ extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, i
         return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)Ng * sizeof(float);
     }
     const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
-    if (pl.splits <= 1) return 0;
-    const size_t plain = (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float);
-    const size_t fused = fused_slab_bytes(pl, pl.n_tiles);
-    return fused < (1ull << 31) && fused > plain ? fused : plain;
+    return pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
 }
 
 // w_krsc (optional): weights re-laid out as [K][KH*KW][C] (rg_weights_to_krsc); with C % 16 == 0 it selects the
@@ -1725,7 +1500,7 @@ extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, i
 extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc, float* y, int N, int C, int H, int W,
                              int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* scale,
                              const float* shift, const float* residual, int act, float slope, void* workspace,
-                             size_t workspace_bytes, int* tile_counters, hipStream_t stream) {
+                             size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_fwd", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(x && w && y, "rg_conv2d_fwd: null tensor");
     ConvP p;
@@ -1772,17 +1547,10 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = (unsigned)need;
-    if (pl.splits > 1 && tile_counters && fused_splitk() && p.m_tiles * p.n_tiles <= RG_TILE_COUNTERS) {
-        const size_t fused = fused_slab_bytes(pl, p.n_tiles);
-        if (fused <= workspace_bytes && fused < (1ull << 31)) {
-            p.counters = tile_counters;
-            p.partial_bytes = (unsigned)fused;
-        }
-    }
     rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
     const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
     RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH);
-    if (pl.splits > 1 && !p.counters) {
+    if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
         hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * p.Ng)), dim3(256), 0, stream,
                            p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
@@ -1800,10 +1568,7 @@ extern "C" int rg_conv_set_force(int tile, int splits) {
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
     if (SH != 1 || SW != 1) return 0;
     const GemmPlan pl = plan_gemm(C, (int64_t)N * H * W, (int64_t)K * KH * KW, true);
-    if (pl.splits <= 1) return 0;
-    const size_t plain = (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float);
-    const size_t fused = fused_slab_bytes(pl, pl.n_tiles);
-    return fused < (1ull << 31) && fused > plain ? fused : plain;
+    return pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
 }
 
 // w_krsc: the weights re-laid out as [K][KH*KW][C] by rg_weights_to_krsc (may be NULL; for 1x1 filters the
@@ -1814,7 +1579,7 @@ namespace {
 int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K, int KH, int KW,
                int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift, const float* residual,
                int act, float slope, const float* relu_mask, float* rowsum, int rowsum_cols, void* workspace,
-               size_t workspace_bytes, int* tile_counters, hipStream_t stream, int* dry) {
+               size_t workspace_bytes, hipStream_t stream, int* dry) {
     if (int e = validate("rg_conv2d_dgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(dry || (dy && w && dx), "rg_conv2d_dgrad: null tensor");
     RG_REQUIRE(SH <= 2 && SW <= 2, "rg_conv2d_dgrad: stride > 2 not supported (got %d,%d)", SH, SW);
@@ -1926,17 +1691,10 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = (unsigned)need;
-    if (pl.splits > 1 && tile_counters && fused_splitk() && p.m_tiles * nt_max <= RG_TILE_COUNTERS) {
-        const size_t fused = fused_slab_bytes(pl, nt_max);
-        if (fused <= workspace_bytes && fused < (1ull << 31)) {
-            p.counters = tile_counters;
-            p.partial_bytes = (unsigned)fused;
-        }
-    }
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
     RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
-    if (pl.splits > 1 && !p.counters) {
+    if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
         hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * ng_max)), dim3(256), 0, stream,
                            p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
@@ -1949,9 +1707,9 @@ extern "C" int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_k
                                int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q,
                                const float* scale, const float* shift, const float* residual, int act, float slope,
                                const float* relu_mask, float* rowsum, int rowsum_cols, void* workspace,
-                               size_t workspace_bytes, int* tile_counters, hipStream_t stream) {
+                               size_t workspace_bytes, hipStream_t stream) {
     return dgrad_impl(dy, w, w_krsc, dx, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, scale, shift, residual, act, slope,
-                      relu_mask, rowsum, rowsum_cols, workspace, workspace_bytes, tile_counters, stream, nullptr);
+                      relu_mask, rowsum, rowsum_cols, workspace, workspace_bytes, stream, nullptr);
 }
 
 // Number of row-sum column blocks rg_conv2d_dgrad writes for this geometry when given the workspace of
@@ -1960,7 +1718,7 @@ extern "C" int rg_conv2d_dgrad_rowsum_cols(int N, int C, int H, int W, int K, in
                                            int P, int Q) {
     int cols = 0;
     if (dgrad_impl(nullptr, nullptr, nullptr, nullptr, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, nullptr, nullptr, nullptr,
-                   0, 0.f, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, &cols) != RG_OK)
+                   0, 0.f, nullptr, nullptr, 0, nullptr, 0, nullptr, &cols) != RG_OK)
         return 0;
     return cols;
 }
@@ -2022,9 +1780,9 @@ extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW,
     return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
 }
 
-namespace {
-int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW,
-               int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes, hipStream_t stream, const BnFold* bf) {
+extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH,
+                               int KW, int SH, int SW, int PH, int PW, int P, int Q, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_wgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(x && dy && dw, "rg_conv2d_wgrad: null tensor");
     RG_REQUIRE(KH < 65536 && KW < 65536, "rg_conv2d_wgrad: filter too large");
@@ -2033,7 +1791,6 @@ int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, 
     p.x = x; p.w = dy;
     p.ep = Epilogue{nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0};
     p.M = K; p.Ng = C * KH * KW; p.Kg = N * P * Q;
-    RG_REQUIRE(!bf || !thin_filter(K, KH, KW), "rg_conv2d_wgrad_bnfold: one-output-channel filters have no BatchNorm pair");
     if (thin_filter(K, KH, KW)) {
         const int per = thin_wgrad_per_slice(C, p.Kg);
         const int slices = rg::cdiv(p.Kg, per);
@@ -2087,40 +1844,11 @@ int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, 
         }
 #undef RG_WGRAD_LAUNCH
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
-        if (bf) {
-            // the pair's finishing pass rides on the split-K sum (splits == 1: the kernel wrote G to dw, summed "in place")
-            RG_REQUIRE(!rsc, "rg_conv2d_wgrad_bnfold: not available with RG_WGRAD_RSC");
-            const float* src = via_ws ? static_cast<const float*>(workspace) : dw;
-            hipLaunchKernelGGL(splitk_reduce_bnfold_kernel, dim3(K), dim3(256), 0, stream, src, dw, p.Ng, (int64_t)p.M * p.Ng,
-                               via_ws ? pl.splits : 1, *bf);
-        } else if (via_ws) {
+        if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
                                static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
         }
     }
     return rg::check_launch("rg_conv2d_wgrad(reduce)");
-}
-}  // namespace
-
-extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH,
-                               int KW, int SH, int SW, int PH, int PW, int P, int Q, void* workspace,
-                               size_t workspace_bytes, hipStream_t stream) {
-    return wgrad_impl(x, dy, dw, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, workspace, workspace_bytes, stream, nullptr);
-}
-
-// Weight gradient of a convolution whose BatchNorm (frozen statistics) is folded into it (csrc/norm.hip, "conv + frozen-
-// statistics BatchNorm"): dw = scale[k] * G with G = wgrad(x, g), dgamma[k] = invstd[k] * (sum_m w[k][m] G[k][m] - mean[k] * sum_g[k]),
-// sum_g given directly or as `n_slices` partials per channel (then also written to dbeta) — one launch less per layer than
-// rg_conv2d_wgrad + rg_bn_fold_wgrad.
-extern "C" int rg_conv2d_wgrad_bnfold(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH,
-                                      int KW, int SH, int SW, int PH, int PW, int P, int Q, void* workspace,
-                                      size_t workspace_bytes, const float* w, const float* scale, const float* invstd,
-                                      const float* running_mean, const float* sum_g, const float* partials, int n_slices,
-                                      float* dbeta, float* dgamma, hipStream_t stream) {
-    RG_REQUIRE(w && scale, "rg_conv2d_wgrad_bnfold: filters and scale are required");
-    RG_REQUIRE(!dgamma || (invstd && running_mean && (sum_g || partials)), "rg_conv2d_wgrad_bnfold: dgamma needs invstd, mean and the sums");
-    RG_REQUIRE(!partials || n_slices > 0, "rg_conv2d_wgrad_bnfold: partials need their slice count");
-    BnFold bf{w, scale, invstd, running_mean, sum_g, partials, n_slices, dbeta, dgamma};
-    return wgrad_impl(x, dy, dw, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, workspace, workspace_bytes, stream, &bf);
 }

@@ -110,7 +110,9 @@ __device__ __forceinline__ unsigned mix32(unsigned long long z) {
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p,
-                               unsigned long long seed) {
+                               unsigned long long seed, const unsigned long long* __restrict__ clock) {
+    // `clock` (optional): a device-side step counter mixed into the seed, so a captured launch draws a new mask per replay
+    if (clock) seed += 0xD1B54A32D192ED03ull * *clock;
     const unsigned thr = (unsigned)fminf(p * 4294967296.f, 4294967295.f);
     const float sc = 1.f / (1.f - p);
     RG_GRID_STRIDE(i, n) {
@@ -225,8 +227,19 @@ extern "C" int rg_dropout(const float* x, float* y, int64_t n, float p, unsigned
     RG_REQUIRE(x && y && n >= 0 && p >= 0.f && p < 1.f, "rg_dropout: bad arguments");
     if (n == 0) return RG_OK;
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * n);
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, p, seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, p, seed, (const unsigned long long*)nullptr);
     return rg::check_launch("rg_dropout");
+}
+
+// the same mask function with seed + 0xD1B54A32D192ED03 * *clock: the forward and the backward launch of one step read the same
+// clock value, a replayed hipGraph draws a fresh mask every time the clock is advanced (rg_u64_add)
+extern "C" int rg_dropout_clocked(const float* x, float* y, int64_t n, float p, unsigned long long seed,
+                                  const unsigned long long* clock, hipStream_t stream) {
+    RG_REQUIRE(x && y && clock && n >= 0 && p >= 0.f && p < 1.f, "rg_dropout_clocked: bad arguments");
+    if (n == 0) return RG_OK;
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, p, seed, clock);
+    return rg::check_launch("rg_dropout_clocked");
 }
 
 extern "C" int rg_l2norm_rows_fwd(const float* x, float* y, float* norm, int rows, int D, float eps,

@@ -51,6 +51,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Device-side Adam clock (so that a captured hipGraph replays correct bias corrections): double state[4] =
+// {step, beta1^step, beta2^step, -}; advanced once per optimizer step, read by adam_dev_kernel.
+__global__ void adam_advance_kernel(double* __restrict__ st, double beta1, double beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st[0] += 1.0;
+        st[1] *= beta1;
+        st[2] *= beta2;
+    }
+}
+
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                                const double* __restrict__ st, float grad_scale) {
+    const float bc1 = (float)(1.0 - st[1]);
+    const float bc2_sqrt = (float)sqrt(1.0 - st[2]);
+    const float step_size = lr / bc1;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float gg = g[e] * grad_scale + wd * p[e];
+        const float mm = beta1 * m[e] + (1.f - beta1) * gg;
+        const float vv = beta2 * v[e] + (1.f - beta2) * gg * gg;
+        m[e] = mm;
+        v[e] = vv;
+        p[e] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void u64_add_kernel(unsigned long long* __restrict__ p, unsigned long long v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
+}
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n,
                            float lr, float momentum, float wd, int first_step, float grad_scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -88,4 +118,28 @@ extern "C" int rg_sgd_step(float* p, const float* g, float* momentum_buf, int64_
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, momentum_buf, n, lr, momentum,
                        weight_decay, first_step, grad_scale);
     return rg::check_launch("rg_sgd_step");
+}
+
+// ---- device-side clocks: the forms a captured hipGraph can replay (no per-step values in the kernel arguments) ---------
+extern "C" int rg_adam_advance(double* state, float beta1, float beta2, hipStream_t stream) {
+    RG_REQUIRE(state, "rg_adam_advance: null state");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, state, (double)beta1, (double)beta2);
+    return rg::check_launch("rg_adam_advance");
+}
+
+// Adam update whose bias corrections come from the device clock {step, beta1^step, beta2^step} (rg_adam_advance)
+extern "C" int rg_adam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, const double* state, float grad_scale,
+                                hipStream_t stream) {
+    RG_REQUIRE(p && g && exp_avg && exp_avg_sq && state && n > 0, "rg_adam_step_dev: bad arguments");
+    rg::ProfScope prof(rg::FAM_OPTIM, stream, 0.0, 28.0 * n);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, weight_decay, state, grad_scale);
+    return rg::check_launch("rg_adam_step_dev");
+}
+
+extern "C" int rg_u64_add(unsigned long long* p, unsigned long long v, hipStream_t stream) {
+    RG_REQUIRE(p, "rg_u64_add: null pointer");
+    hipLaunchKernelGGL(u64_add_kernel, dim3(1), dim3(64), 0, stream, p, v);
+    return rg::check_launch("rg_u64_add");
 }

@@ -289,5 +289,4 @@ class VGGLoss(nn.Module):
 
 def _wsum(terms):
     vals = torch.stack([t for t, _ in terms])
-    w = torch.tensor([float(w) for _, w in terms], dtype=torch.float32).to(vals.device, non_blocking=True)
-    return RF._WeightedSum.apply(vals, w, 1.0)
+    return RF._WeightedSum.apply(vals, RF.const_vector(tuple(float(w) for _, w in terms), vals.device), 1.0)

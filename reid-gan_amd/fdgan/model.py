@@ -43,8 +43,7 @@ from rg_hip.tape import no_param_grad
 def _weighted(terms):
     """sum_i w_i * loss_i of 0-dim device losses in one kernel (keeps the autograd graph)."""
     vals = torch.stack([t for t, _ in terms])
-    w = torch.tensor([float(w) for _, w in terms], dtype=torch.float32).to(vals.device, non_blocking=True)
-    return RF._WeightedSum.apply(vals, w, 1.0)
+    return RF._WeightedSum.apply(vals, RF.const_vector(tuple(float(w) for _, w in terms), vals.device), 1.0)
 
 
 class FDGANModel(object):

@@ -8,6 +8,19 @@ import torch
 from . import ops
 
 
+_CONST = {}
+
+
+def const_vector(values, device):
+    """a cached fp32 device vector of compile-time constants (loss weights): one host->device copy per distinct tuple, none on
+    the step path afterwards (pageable H2D copies are neither asynchronous nor capturable into a hipGraph)"""
+    key = (values, device.index)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.tensor(values, dtype=torch.float32).to(device)
+    return t
+
+
 def _scalar_grad(g):
     """a 0-dim upstream gradient as a 1-element contiguous device tensor (or None)."""
     if g is None:

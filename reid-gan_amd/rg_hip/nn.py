@@ -22,7 +22,10 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
+import weakref
+
 WEIGHT_EPOCH = [0]      # bumped by rg_hip.optim after every step (its kernels bypass torch's version counters)
+BN_LAYERS = weakref.WeakSet()      # rg_hip.graph advances their host-side `num_batches_tracked` bookkeeping per replay
 
 
 class _KrscCache(object):
@@ -267,6 +270,7 @@ class Linear(RGModule):
 class _BatchNorm(RGModule):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super(_BatchNorm, self).__init__()
+        BN_LAYERS.add(self)
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
         self.affine, self.track_running_stats = affine, track_running_stats
         if affine:
@@ -527,16 +531,11 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
         og = tape.grad_out(bn.weight) if want_g else None
         dgamma = (og if og is not None else torch.empty_like(f.scale)) if want_g else None
 
-        # the pair's finishing pass (dw = scale * G, dgamma, dbeta from the slice partials) rides on the split-K sum
-        fold = dict(w=w, scale=f.scale, invstd=f.invstd, mean=bn.running_mean, sum_g=sg, partials=part,
-                    dbeta=dbeta if part is not None else None, dgamma=dgamma)
-        if conv.weight.shape[0] == 1 and conv.weight.shape[2] * conv.weight.shape[3] > 1:
-            fold, after = None, (lambda G: ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
-                                                             dbeta=dbeta if part is not None else None))
-        else:
-            after = None
+        def finish(G):
+            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
+                              dbeta=dbeta if part is not None else None)
         dw = ops.conv2d_wgrad(x, g, conv.weight.shape, conv.stride, conv.padding,
-                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=after, bnfold=fold)
+                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=finish)
         if want_w:
             tape.add_grad(conv.weight, dw)
         if want_g:

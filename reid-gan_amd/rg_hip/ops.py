@@ -60,24 +60,6 @@ class _Workspace(object):
 _ws = _Workspace()
 
 
-class _TileCounters(object):
-    """Arrival counters of the in-kernel split-K reductions (rg_conv2d_fwd / dgrad `tile_counters`): RG_TILE_COUNTERS zero
-    ints per (device, stream) — launches on one stream are ordered and every launch leaves the buffer zero."""
-
-    def __init__(self):
-        self.bufs = {}
-
-    def get(self, device):
-        key = (device.index, _stream())
-        buf = self.bufs.get(key)
-        if buf is None:
-            buf = self.bufs[key] = torch.zeros(16384, dtype=torch.int32, device=device)
-        return buf
-
-
-_tc = _TileCounters()
-
-
 _ws_sizes = {}
 
 
@@ -133,8 +115,7 @@ def conv2d_fwd(x, w, stride=1, padding=0, scale=None, shift=None, residual=None,
     nbytes = _ws_query("rg_conv2d_fwd_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device) if nbytes else None
     lib.rg_conv2d_fwd(_p(x), _p(w), _p(w_krsc), _p(y), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale), _p(shift),
-                      _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0,
-                      _p(_tc.get(x.device)) if ws is not None else None, _stream())
+                      _p(residual), act, slope, _p(ws), ws.numel() if ws is not None else 0, _stream())
     return y
 
 
@@ -169,7 +150,7 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
             rowsum = torch.empty((C, cols), dtype=torch.float32, device=dy.device)
     lib.rg_conv2d_dgrad(_p(dy), _p(w), _p(w_krsc), _p(dx), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(scale),
                         _p(shift), _p(residual), act, slope, _p(relu_mask), _p(rowsum), cols, _p(ws),
-                        ws.numel() if ws is not None else 0, _p(_tc.get(dy.device)) if ws is not None else None, _stream())
+                        ws.numel() if ws is not None else 0, _stream())
     if rowsum is not None:
         dx._rg_rowsum = rowsum          # rides with the gradient to the BatchNorm fold of the layer below (nn.conv_bn_tb)
     return dx
@@ -233,10 +214,9 @@ def side_join():
         sess.used = False
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None, bnfold=None):
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
     """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
-    behind the wgrad kernels on the same stream.  bnfold = dict(w, scale, invstd, mean, sum_g | partials, dbeta, dgamma):
-    the finishing pass of a (conv, frozen BatchNorm) pair rides on the split-K sum (rg_conv2d_wgrad_bnfold)."""
+    behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
     if side and _SIDE["on"]:
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
@@ -246,8 +226,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
             ev.record(main)
             sess.stream.wait_event(ev)
             with torch.cuda.stream(sess.stream):
-                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after, bnfold=bnfold)
-            sess.refs.append((x, dy, dw, after, bnfold))  # hooks / fold operands stay alive until the join
+                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after)
+            sess.refs.append((x, dy, dw, after))         # the hook's closure keeps ITS operands alive too
             sess.used = True
             return dw
     x, dy = _chk(x, "x"), _chk(dy, "dy")
@@ -261,15 +241,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     nbytes = _ws_query("rg_conv2d_wgrad_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device)
-    if bnfold is not None:
-        part = bnfold.get("partials")
-        lib.rg_conv2d_wgrad_bnfold(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
-                                   _p(bnfold["w"]), _p(bnfold["scale"]), _p(bnfold["invstd"]), _p(bnfold["mean"]),
-                                   _p(bnfold.get("sum_g")), _p(part), part.shape[1] if part is not None else 0,
-                                   _p(bnfold.get("dbeta")), _p(bnfold.get("dgamma")), _stream())
-    else:
-        lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
-                            _stream())
+    lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
+                        _stream())
     if after is not None:
         after(dw)
     return dw
@@ -488,10 +461,27 @@ def sub_square_bwd(a, b, dy, need_a=True, need_b=True):
     return da, db
 
 
+_CLOCK = {}
+
+
+def step_clock(device):
+    """device-side step counter (uint64 as int64 storage) mixed into dropout seeds; advanced by rg_hip.graph per captured step"""
+    c = _CLOCK.get(device.index)
+    if c is None:
+        c = _CLOCK[device.index] = torch.zeros(1, dtype=torch.int64, device=device)
+    return c
+
+
+def advance_step_clock(device):
+    lib.rg_u64_add(_p(step_clock(device)), 1, _stream())
+
+
 def dropout(x, p, seed):
+    """keep iff hash(seed + K * clock, element) >= p 2^32; the clock is 0 unless a captured step advances it (rg_hip.graph), so
+    eager runs reproduce the (seed, index) -> bit function of the oracle exactly"""
     x = _chk(x, "x")
     y = torch.empty_like(x)
-    lib.rg_dropout(_p(x), _p(y), x.numel(), p, seed, _stream())
+    lib.rg_dropout_clocked(_p(x), _p(y), x.numel(), p, seed, _p(step_clock(x.device)), _stream())
     return y
 
 
@@ -897,6 +887,15 @@ def segment_mean(x, order, offsets):
     return out
 
 
+def adam_advance(state, beta1, beta2):
+    lib.rg_adam_advance(_p(state), beta1, beta2, _stream())
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, weight_decay, state, grad_scale=1.0):
+    lib.rg_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, _p(state), grad_scale,
+                         _stream())
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     lib.rg_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                      _stream())
@@ -909,8 +908,19 @@ def sgd_step(p, g, buf, lr, momentum, weight_decay, first_step, grad_scale=1.0):
 # ------------------------------------------------------------------------------------------------
 # profiler
 # ------------------------------------------------------------------------------------------------
+_PROFILING = [False]
+
+
 def profile_enable(on=True):
+    _PROFILING[0] = bool(on)
     lib.rg_profile_enable(int(on))
+
+
+def check_not_profiling():
+    """the per-launch event profiler records timing events on the launch stream: not capturable / meaningless under replay"""
+    if _PROFILING[0]:
+        raise RuntimeError("rg_hip: the launch profiler is on; switch it off (ops.profile_enable(False)) before capturing or "
+                           "replaying a step graph")
 
 
 def profile_reset():

@@ -17,7 +17,11 @@ from torch.optim import Optimizer
 
 from . import ops
 
+import weakref
+
 _ALIGN = 64          # elements; keeps every view 256-byte aligned (float4 kernels, RCCL)
+ARENAS = weakref.WeakSet()          # every live arena / optimizer: rg_hip.graph advances their host-side counters per replay
+OPTIMIZERS = weakref.WeakSet()
 
 
 class Arena(object):
@@ -37,6 +41,7 @@ class Arena(object):
             self.offsets.append(off)
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.size = off
+        ARENAS.add(self)
         self.epoch = 0           # bumped by every optimizer step: invalidates cached filter re-layouts
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -171,6 +176,21 @@ class Adam(_FlatOptimizer):
         self._m = torch.zeros_like(self._arena.flat)
         self._v = torch.zeros_like(self._arena.flat)
         self._steps = [0] * len(self._arena.params)
+        # device-side clocks {step, beta1^step, beta2^step}, one per beta pair: the bias corrections of the fused kernel are
+        # read from device memory, so a captured hipGraph of the step replays correctly (rg_hip.graph)
+        self._clocks = {}
+        OPTIMIZERS.add(self)
+
+    def _clock(self, b1, b2, step):
+        """the device clock for (beta1, beta2) showing `step` completed steps, or None when no clock is at that step (a
+        parameter that joined late): the by-value kernel then serves that range"""
+        c = self._clocks.get((b1, b2))
+        if c is None:
+            if step != 0:
+                return None
+            st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64).to(self._arena.flat.device)
+            c = self._clocks[(b1, b2)] = [st, 0, -1]          # [device state, host mirror of its step, epoch of last advance]
+        return c if c[1] == step or (c[1] == step + 1 and c[2] == self._arena.epoch) else None
 
     def _uniform_state(self, segs):
         """cached runs stay valid while every member of a run still has the run's step count"""
@@ -186,6 +206,7 @@ class Adam(_FlatOptimizer):
 
     def _import_param_state(self, i, o, p, entry):
         n = p.numel()
+        self._clocks = {}                    # resumed step counts: the by-value kernels serve until a fresh optimizer is built
         self._steps[i] = int(entry["step"])
         self._m[o:o + n].copy_(entry["exp_avg"].reshape(-1))
         self._v[o:o + n].copy_(entry["exp_avg_sq"].reshape(-1))
@@ -203,8 +224,16 @@ class Adam(_FlatOptimizer):
             a0, a1, members, key = seg
             lr, b1, b2, eps, wd = key[:5]
             st = self._steps[members[0]]
-            ops.adam_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._m[a0:a1], self._v[a0:a1], lr, b1, b2, eps, wd,
-                          st + 1, self.grad_scale)
+            clock = self._clock(b1, b2, st)
+            if clock is not None:
+                if clock[1] == st:                       # first range of this step with these betas: tick the clock
+                    ops.adam_advance(clock[0], b1, b2)
+                    clock[1], clock[2] = st + 1, a.epoch
+                ops.adam_step_dev(a.flat[a0:a1], a.flat_grad[a0:a1], self._m[a0:a1], self._v[a0:a1], lr, b1, b2, eps, wd,
+                                  clock[0], self.grad_scale)
+            else:
+                ops.adam_step(a.flat[a0:a1], a.flat_grad[a0:a1], self._m[a0:a1], self._v[a0:a1], lr, b1, b2, eps, wd,
+                              st + 1, self.grad_scale)
             for i in members:
                 self._steps[i] = st + 1
             seg[3] = key[:5] + (st + 1,)
@@ -222,6 +251,7 @@ class SGD(_FlatOptimizer):
         self._setup()
         self._buf = torch.zeros_like(self._arena.flat)
         self._started = [False] * len(self._arena.params)
+        OPTIMIZERS.add(self)
 
     def _uniform_state(self, segs):
         st = self._started

@@ -35,7 +35,7 @@ def test_queries_and_error_convention_without_gpu():
         lib.rg_fill(None, 4, 1.0, None)
     assert "rg_fill" in str(e.value)
     with pytest.raises(RuntimeError) as e:       # inconsistent geometry is rejected before any launch
-        lib.rg_conv2d_fwd(1, 1, None, 1, 1, 3, 8, 8, 4, 3, 3, 1, 1, 1, 1, 99, 99, None, None, None, 0, 0.0, None, 0, None, None)
+        lib.rg_conv2d_fwd(1, 1, None, 1, 1, 3, 8, 8, 4, 3, 3, 1, 1, 1, 1, 99, 99, None, None, None, 0, 0.0, None, 0, None)
     assert "rg_conv2d_fwd" in str(e.value)
 
 

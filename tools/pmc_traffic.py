@@ -3,13 +3,15 @@
 per-family HBM traffic.  Units and corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950
 FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled; WRITE_SIZE is exact.
 
-usage: pmc_traffic.py <pmc_fetch_size.csv> <pmc_write_size.csv> <steps in each pass> <out.json>"""
+usage: pmc_traffic.py <pmc_fetch_size.csv> <pmc_write_size.csv> <steps in each pass> <out.json> [config key]
+With a config key the result is merged into out.json under configs[key] (the layout bench.py reads)."""
 import csv
 import json
 import sys
 from collections import defaultdict
 
-FAMILIES = (("conv", ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_splitk_finish", "splitk_reduce", "weights_to_krsc")),
+FAMILIES = (("conv_f8", ("conv_f8", "f8_quantize", "f8_splitk", "f8_amax", "f8_roll")),
+            ("conv", ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_splitk_finish", "splitk_reduce", "weights_to_krsc")),
             ("norm", ("bn_",)), ("optim", ("adam", "sgd")), ("pool", ("maxpool", "global_avgpool", "gem_")))
 
 
@@ -36,6 +38,17 @@ def main():
         res["families"][f] = {"launches_per_step": n[f] / steps, "read_bytes_per_step": rd[f] / steps,
                               "write_bytes_per_step": wr[f] / steps,
                               "bytes_per_launch": (rd[f] + wr[f]) / max(n[f], 1)}
+    if len(sys.argv) > 5:
+        key = sys.argv[5]
+        try:
+            doc = json.load(open(out))
+        except (OSError, ValueError):
+            doc = {"configs": {}}
+        doc.setdefault("configs", {})[key] = res
+        res = doc
+        json.dump(doc, open(out, "w"), indent=1)
+        print(key, json.dumps({f: v for f, v in doc["configs"][key]["families"].items() if f.startswith("conv")}))
+        return
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["families"]["conv"]))
 
