@@ -42,7 +42,11 @@ def init_weights(net, init_type='normal', gain=0.02):
             elif init_type == 'kaiming':
                 init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
             elif init_type == 'orthogonal':
-                init.orthogonal_(m.weight.data, gain=gain)
+                # drawn and factorised on the host (same distribution; the device QR of hipSOLVER is the only library call
+                # the construction would make, and it does not survive rocprofv3's counter collection)
+                w = torch.empty(m.weight.shape, dtype=torch.float32)
+                init.orthogonal_(w, gain=gain)
+                m.weight.data.copy_(w)
             else:
                 raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
             if getattr(m, 'bias', None) is not None:

@@ -40,6 +40,34 @@ def _shift_bn(mod, shift=8.0, seed=0):
                 m.running_var.copy_(0.8 + 0.4 * torch.rand(m.running_var.shape, generator=g))
 
 
+def _calibrate_bn(mod, forward, margin=1.0):
+    """One forward pass of the oracle that lifts every BatchNorm bias, channel by channel, until the smallest value the layer
+    emits on this input is `margin` (+ 1 % of the layer's largest): the residual stream of an untrained ResNet grows into the
+    thousands, so no fixed shift keeps all 53 pre-ReLU maps positive.  Returns the smallest BatchNorm output of a second,
+    unmodified pass (the proof that no ReLU bites)."""
+    lows = []
+
+    def lift(m, inp, out):
+        red = [d for d in range(out.dim()) if d != 1]
+        lo, hi = out.amin(red), out.abs().amax()
+        delta = (margin + 0.01 * hi) - lo
+        with torch.no_grad():
+            m.bias.add_(delta.to(m.bias.dtype))
+        return out + delta.view([1, -1] + [1] * (out.dim() - 2))
+
+    def probe(m, inp, out):
+        lows.append(float(out.min()))
+
+    bns = [m for m in mod.modules() if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d))]
+    for hook in (lift, probe):
+        hs = [m.register_forward_hook(hook) for m in bns]
+        with torch.no_grad():
+            forward()
+        for h in hs:
+            h.remove()
+    return min(lows)
+
+
 def _grads_exact(rg, o64, tol=2e-5, loose=(), loose_tol=2e-3):
     og = dict(o64.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values() if p.grad is not None)
@@ -65,13 +93,14 @@ def test_resnet50_trunk_exact_without_kinks(dev, mode):
     torch.manual_seed(40)
     o = O.OReidResNet(50, cut_at_pooling=True)
     _shift_bn(o, 8.0, 1)
-    r = RM.create('resnet50', cut_at_pooling=True, pretrained=False)
-    r.load_state_dict(o.state_dict())
-    r.to(dev)
+    x = O.synth_images(4, 64, 32, seed=3)
     o = o.double()
     getattr(o, mode)()
+    assert _calibrate_bn(o, lambda: o(x.double())) >= 1.0
+    r = RM.create('resnet50', cut_at_pooling=True, pretrained=False)
+    r.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in o.state_dict().items()})
+    r.to(dev)
     getattr(r, mode)()
-    x = O.synth_images(4, 64, 32, seed=3)
     xo = x.double().clone().requires_grad_(True)
     xr = x.clone().to(dev).requires_grad_(True)
     yo, yr = o(xo), r(xr)
@@ -95,16 +124,17 @@ def test_pose_generator_exact_without_kinks(dev):
     o.apply(O.o_weights_init_normal)
     _shift_bn(o, 8.0, 2)
     with torch.no_grad():
-        o.en_conv1[0].weight.abs_()                       # no norm behind it: positive filters on positive pose maps
+        o.en_conv1.weight.abs_()                       # no norm behind it: positive filters on positive pose maps
     r = N.CustomPoseGenerator(128, 2048, 256, dropout=0.0, norm_layer=N.get_norm_layer('batch'), fuse_mode='cat',
                               connect_layers=0)
-    r.load_state_dict(o.state_dict())
-    r.to(dev).train()
     o = o.double().train()
     g = torch.Generator().manual_seed(4)
     pose = O.synth_posemaps(3, seed=3) + 0.5
     feat = torch.randn(3, 2048, 1, 1, generator=g).abs() + 0.1
     z = torch.randn(3, 256, 1, 1, generator=g).abs() + 0.1
+    assert _calibrate_bn(o, lambda: o(pose.double(), feat.double(), z.double())) >= 1.0
+    r.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in o.state_dict().items()})
+    r.to(dev).train()
     fo = feat.double().clone().requires_grad_(True)
     fr = feat.clone().to(dev).requires_grad_(True)
     yo = o(pose.double(), fo, z.double())
