@@ -341,7 +341,7 @@ class DPTNStep(Workload):
     peak = F8_MFMA_PEAK_TFLOPS
     conv_families = ("conv_f8",)
     kernel_note = ("fp8 conv implicit-GEMM family (conv_f8_*_kernel: e4m3 activations / weights, e5m2 gradients, per-tensor "
-                   "scales, fp32 accumulate, v_mfma_f32_16x16x32_fp8_fp8 / _bf8_fp8)")
+                   "scales, fp32 accumulate, v_mfma_f32_32x32x16_fp8_fp8 / _bf8_fp8 / _fp8_bf8)")
     describe = ("dual_gan two-generator path: DPTNModel.optimize_parameters (DPTN_model.py:216-225; source->source and "
                 "source->target branches of DPTNGenerator, ResDiscriminator on the target branch), fp8 MFMA convolutions, "
                 "64 crops of 128x64 per GPU, hinge GAN loss, perceptual loss off (VGG-19 weights need a download)")

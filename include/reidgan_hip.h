@@ -106,6 +106,9 @@ int rg_bn_apply_fwd(const float* x, const float* mean, const float* stat, const 
 int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
                      float* sum_dy, float* sum_dy_xhat, int N, int C, int HW, int stat_is_var, float eps, int act,
                      float slope, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+/* out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c]: dgamma / dbeta of an affine InstanceNorm2d (torch.nn.InstanceNorm2d
+ * backward as used by CC/dual_gan/models/base_function.py:38-49) from the per-(n,c) sums of rg_bn_bwd_reduce. */
+int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C, rg_stream_t stream);
 int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
                     const float* gamma, const float* sum_dy, const float* sum_dy_xhat, float* dx, float* dres, int N,
                     int C, int HW, int train, int stat_is_var, float eps, int act, float slope, rg_stream_t stream);

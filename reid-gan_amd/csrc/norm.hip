@@ -619,6 +619,29 @@ extern "C" int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_
     return rg::check_launch("rg_bn_bwd_reduce");
 }
 
+// out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c] (ascending n): the affine gradients of an InstanceNorm from the per-(n,c) sums
+// its backward reduction already produced.  Either pair may be NULL.
+__global__ void rows_sum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ oa,
+                                     float* __restrict__ ob, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sa = 0.f, sb = 0.f;
+    for (int n = 0; n < N; ++n) {
+        if (a) sa += a[(int64_t)n * C + c];
+        if (b) sb += b[(int64_t)n * C + c];
+    }
+    if (a) oa[c] = sa;
+    if (b) ob[c] = sb;
+}
+
+extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C,
+                                hipStream_t stream) {
+    RG_REQUIRE((a || b) && (!a || out_a) && (!b || out_b) && N > 0 && C > 0, "rg_rows_sum_pair: bad arguments");
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * ((a ? 1 : 0) + (b ? 1 : 0)) * (double)(N + 1) * C);
+    hipLaunchKernelGGL(rows_sum_pair_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, a, b, out_a, out_b, N, C);
+    return rg::check_launch("rg_rows_sum_pair");
+}
+
 // dx (may be NULL) and dres (may be NULL; the gradient of a fused residual input = dy*act'(y)).
 extern "C" int rg_bn_bwd_apply(const float* x, const float* dy, const float* y_act, const float* mean,
                                const float* stat, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,

@@ -676,12 +676,21 @@ class InstanceNorm2d(RGModule):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
+    def _tiled_affine(self, N):
+        """gamma / beta repeated per sample (the kernels see N*C channels), rebuilt only when the parameters changed"""
+        w = self.weight
+        arena = getattr(w, "_rg_arena", None)
+        key = (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, self.bias._version, w.data_ptr(), N)
+        if self.__dict__.get("_tiled_key") != key:
+            self.__dict__["_tiled"] = (w.detach().repeat(N), self.bias.detach().repeat(N))
+            self.__dict__["_tiled_key"] = key
+        return self.__dict__["_tiled"]
+
     def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
         N, C = x.shape[0], x.shape[1]
         xv = x.reshape(1, N * C, *x.shape[2:])
         mean, invstd = ops.bn_stats(xv, None, None, self.eps, 0.0)
-        g = self.weight.detach().repeat(N) if self.affine else None
-        b = self.bias.detach().repeat(N) if self.affine else None
+        g, b = self._tiled_affine(N) if self.affine else (None, None)
         rv = residual.reshape(xv.shape) if residual is not None else None
         y = ops.bn_apply_fwd(xv, mean, invstd, g, b, rv, False, self.eps, act, slope)
         tape.push((xv, y if act != ACT_NONE else None, mean, invstd, g, act, slope, residual is not None, x.shape))
@@ -693,9 +702,9 @@ class InstanceNorm2d(RGModule):
         dyv = dy.reshape(xv.shape)
         s1, s2 = ops.bn_bwd_reduce(xv, dyv, y, mean, invstd, False, self.eps, act, slope)
         if self.affine and tape.wants(self.weight):
-            ones = ops.fill_(torch.empty(1, N, dtype=torch.float32, device=dy.device), 1.0)
-            tape.add_grad(self.weight, ops.linear_fwd(ones, s2.view(N, C).t().contiguous()).view(C))
-            tape.add_grad(self.bias, ops.linear_fwd(ones, s1.view(N, C).t().contiguous()).view(C))
+            dg, db = ops.rows_sum_pair(s2, s1, N, C, tape.grad_out(self.weight), tape.grad_out(self.bias))
+            tape.add_grad(self.weight, dg)
+            tape.add_grad(self.bias, db)
         dx, dres = ops.bn_bwd_apply(xv, dyv, y, mean, invstd, g, s1, s2, True, False, self.eps, act, slope,
                                     need_dx=True, need_dres=has_res)
         dx = dx.view(shape)

@@ -311,6 +311,17 @@ def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT
     return sum_dy, sum_dy_xhat
 
 
+def rows_sum_pair(a, b, N, C, out_a=None, out_b=None):
+    """column sums of two [N][C] matrices in one launch (InstanceNorm affine gradients)."""
+    dev = (a if a is not None else b).device
+    if a is not None and out_a is None:
+        out_a = torch.empty(C, dtype=torch.float32, device=dev)
+    if b is not None and out_b is None:
+        out_b = torch.empty(C, dtype=torch.float32, device=dev)
+    lib.rg_rows_sum_pair(_p(a), _p(b), _p(out_a), _p(out_b), N, C, _stream())
+    return out_a, out_b
+
+
 def bn_bwd_apply(x, dy, y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, train, stat_is_var=False, eps=1e-5,
                  act=ACT_NONE, slope=0.0, need_dx=True, need_dres=False):
     x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
@@ -399,10 +410,21 @@ def channel_sum(dy, out=None):
     """sum over N and HW of dy[N][C][HW] (bias gradient)."""
     dy = _chk(dy, "dy")
     N, C, HW = _nchw(dy)
-    zero = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 0.0)
-    one = fill_(torch.empty(C, dtype=torch.float32, device=dy.device), 1.0)
-    s, _ = bn_bwd_reduce(dy, dy, None, zero, one, out_sum_dy=out)
+    s, _ = bn_bwd_reduce(dy, dy, None, const_fill(C, 0.0, dy.device), const_fill(C, 1.0, dy.device), out_sum_dy=out)
     return s
+
+
+_CONST_FILL = {}
+
+
+def const_fill(n, v, device):
+    """a cached read-only device vector of n copies of v (identity mean / invstd, unit cotangents): filled once, never on the
+    step path afterwards"""
+    key = (n, float(v), device.index)
+    t = _CONST_FILL.get(key)
+    if t is None:
+        t = _CONST_FILL[key] = fill_(torch.empty(n, dtype=torch.float32, device=device), v)
+    return t
 
 
 # ------------------------------------------------------------------------------------------------

@@ -23,3 +23,7 @@ for c in 5 3 4b; do
   done
   python tools/pmc_traffic.py gpurun_out/r02_c${c}_pmc_FETCH_SIZE.csv gpurun_out/r02_c${c}_pmc_WRITE_SIZE.csv 2 gpurun_out/r02_pmc_traffic.json $c | tee -a gpurun_out/r02h_status.txt
 done
+for c in 5 2 4a; do
+  timeout -k 10 300 python tools/debug/aten_callers.py $c > gpurun_out/r02h_aten_$c.txt 2>&1; echo "aten $c rc=$?" | tee -a gpurun_out/r02h_status.txt
+  timeout -k 10 300 python tools/debug/host_cost.py $c > gpurun_out/r02h_host_$c.txt 2>&1; echo "host $c rc=$?" | tee -a gpurun_out/r02h_status.txt
+done
