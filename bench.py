@@ -44,8 +44,8 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
-F8_MFMA_PEAK_TFLOPS = 2500.0      # non-scaled fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8) issues at the bf16 rate (same guide,
-                                  # "Matrix cores": 'so the BF16 rate'); only the block-scaled MX forms reach ~5 PF
+F8_MFMA_PEAK_TFLOPS = 5000.0      # dense fp8: v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 / e5m2 operands runs at twice the
+                                  # bf16 rate (same guide, "Matrix cores"); the non-scaled 32x32x16 fp8 forms only reach 2.5 PF
 METRIC = "train-step images/sec, 256×128 ReID batch, 1/2/4/8 MI355X"
 
 
@@ -341,7 +341,7 @@ class DPTNStep(Workload):
     peak = F8_MFMA_PEAK_TFLOPS
     conv_families = ("conv_f8",)
     kernel_note = ("fp8 conv implicit-GEMM family (conv_f8_*_kernel: e4m3 activations / weights, e5m2 gradients, per-tensor "
-                   "scales, fp32 accumulate, v_mfma_f32_32x32x16_fp8_fp8 / _bf8_fp8 / _fp8_bf8)")
+                   "scales, fp32 accumulate, v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales)")
     describe = ("dual_gan two-generator path: DPTNModel.optimize_parameters (DPTN_model.py:216-225; source->source and "
                 "source->target branches of DPTNGenerator, ResDiscriminator on the target branch), fp8 MFMA convolutions, "
                 "64 crops of 128x64 per GPU, hinge GAN loss, perceptual loss off (VGG-19 weights need a download)")

@@ -255,10 +255,11 @@ int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W
 int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int pad, rg_stream_t stream);
 /* torch.nn.utils.spectral_norm (base_function.py:121-126; every ResDiscriminator conv, networks.py:917-955) on the
  * filter viewed as W[K][M]: training != 0 runs one power iteration in place on u[K], v[M] (eps-clamped norms), then
- * sigma = u.(W v); writes w_sn = W / sigma and sigma[0] = sigma, sigma[1] = 1 / sigma (device, 2 floats).
+ * sigma = u.(W v); writes w_sn = W / sigma and sigma[0] = sigma, sigma[1] = 1 / sigma (device, 2 floats); uv_saved (may be NULL,
+ * K + M floats) receives the u, v this forward used — the constants of its backward, which the next forward overwrites.
  * K <= 1024, M <= 12288.  Backward: dw (+)= (dw_sn - (sum dw_sn * w_sn) u v^T) / sigma with the forward's u, v. */
-int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, int K, int M, int training,
-                         float eps, rg_stream_t stream);
+int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* uv_saved, int K, int M,
+                         int training, float eps, rg_stream_t stream);
 int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
                          float* dw, int K, int M, int accumulate, rg_stream_t stream);
 /* Batched strided fp32 GEMM (MFMA) for nn.MultiheadAttention inside CAB / TTB, PTM.py:162-247:

@@ -96,7 +96,8 @@ constexpr int SN_MAX_M = 12288;         // v (and W^T u) live in LDS
 
 __global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const float* __restrict__ w, float* __restrict__ u,
                                                                         float* __restrict__ v, float* __restrict__ sigma_out,
-                                                                        int K, int M, int training, float eps) {
+                                                                        float* __restrict__ uv_saved, int K, int M, int training,
+                                                                        float eps) {
     __shared__ float vs[SN_MAX_M];
     __shared__ float us[1024];
     __shared__ float ss[1024];
@@ -119,9 +120,13 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const f
             const float t = vs[m] * inv;
             vs[m] = t;
             v[m] = t;
+            if (uv_saved) uv_saved[K + m] = t;
         }
     } else {
-        for (int m = tid; m < M; m += SN_THREADS) vs[m] = v[m];
+        for (int m = tid; m < M; m += SN_THREADS) {
+            vs[m] = v[m];
+            if (uv_saved) uv_saved[K + m] = vs[m];
+        }
     }
     __syncthreads();
     // s = W v: one wave per row
@@ -141,10 +146,14 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const f
         for (int k = tid; k < K; k += SN_THREADS) {
             const float un = ss[k] * inv;
             u[k] = un;
+            if (uv_saved) uv_saved[k] = un;
             dotp += un * ss[k];
         }
     } else {
-        for (int k = tid; k < K; k += SN_THREADS) dotp += us[k] * ss[k];
+        for (int k = tid; k < K; k += SN_THREADS) {
+            dotp += us[k] * ss[k];
+            if (uv_saved) uv_saved[k] = us[k];
+        }
     }
     const float sigma = rg_block_sum(dotp, red);
     if (tid == 0) {
@@ -217,13 +226,14 @@ extern "C" int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C,
     return rg::check_launch("rg_reflection_pad2d_bwd");
 }
 
-extern "C" int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, int K, int M,
-                                    int training, float eps, hipStream_t stream) {
+extern "C" int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* uv_saved, int K,
+                                    int M, int training, float eps, hipStream_t stream) {
     RG_REQUIRE(w && u && v && w_sn && sigma && K > 0 && M > 0, "rg_spectral_norm_fwd: bad arguments");
     RG_REQUIRE(K <= 1024 && M <= SN_MAX_M, "rg_spectral_norm_fwd: matrix %d x %d exceeds the single-workgroup limits (1024 x %d)",
                K, M, SN_MAX_M);
     rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 12.0 * K * M);
-    hipLaunchKernelGGL(spectral_norm_power_kernel, dim3(1), dim3(SN_THREADS), 0, stream, w, u, v, sigma, K, M, training, eps);
+    hipLaunchKernelGGL(spectral_norm_power_kernel, dim3(1), dim3(SN_THREADS), 0, stream, w, u, v, sigma, uv_saved, K, M, training,
+                       eps);
     const int64_t n = (int64_t)K * M;
     hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w, w_sn, sigma + 1, n);
     return rg::check_launch("rg_spectral_norm_fwd");

@@ -463,9 +463,10 @@ class ResDiscriminator(RGModule):
     def _gp_weight(conv, training):
         """effective filter of one convolution for this forward: (w, w_krsc, spectral-norm record or None)"""
         if isinstance(conv, rnn.SNConv2d):
-            w_sn, sigma = ops.spectral_norm_fwd(conv.weight_orig.detach(), conv.weight_u, conv.weight_v, training, conv.eps)
+            w_sn, sigma, u, v = ops.spectral_norm_fwd(conv.weight_orig.detach(), conv.weight_u, conv.weight_v, training, conv.eps,
+                                                      save_uv=True)
             conv.weight = w_sn
-            rec = (sigma, conv.weight_u.clone(), conv.weight_v.clone())
+            rec = (sigma, u, v)
             w = w_sn
         else:
             w, rec = conv.weight.detach(), None

@@ -30,16 +30,17 @@ from . import ops
 
 
 def _counters():
-    """[(get, set)] accessors of every host-side integer the step code advances"""
+    """{key: (get, set)} accessors of every host-side integer the step code advances; the key identifies the counter's owner, so
+    two snapshots can be compared even when unrelated objects were garbage-collected in between"""
     from . import nn as rnn
     from . import optim as roptim
-    acc = []
+    acc = {}
 
     def attr(obj, name):
-        acc.append((lambda: getattr(obj, name), lambda v: setattr(obj, name, v)))
+        acc[(id(obj), name)] = (lambda: getattr(obj, name), lambda v: setattr(obj, name, v))
 
     def item(seq, i):
-        acc.append((lambda: seq[i], lambda v: seq.__setitem__(i, v)))
+        acc[(id(seq), i)] = (lambda: seq[i], lambda v: seq.__setitem__(i, v))
 
     for a in list(roptim.ARENAS):
         attr(a, "epoch")
@@ -54,7 +55,7 @@ def _counters():
     for bn in list(rnn.BN_LAYERS):
         d = bn.__dict__
         d.setdefault("_nbt_pending", 0)
-        acc.append((lambda d=d: d["_nbt_pending"], lambda v, d=d: d.__setitem__("_nbt_pending", v)))
+        item(d, "_nbt_pending")
     item(rnn.WEIGHT_EPOCH, 0)
     return acc
 
@@ -92,20 +93,20 @@ class CapturedStep(object):
         ops.check_not_profiling()
         torch.cuda.synchronize(self.device)
         acc = _counters()
-        before = [g() for g, _ in acc]
+        before = {k: g() for k, (g, _) in acc.items()}
         self.graph = torch.cuda.CUDAGraph()
         kw = {} if self.pool is None else {"pool": self.pool}
         with torch.cuda.graph(self.graph, **kw):
             ops.advance_step_clock(self.device)
             self.out = self.fn()
-        # counters created during the capture (lazily built clocks) are picked up here as well
-        acc2 = _counters()
-        self.deltas = []
-        for (g, s_), b in zip(acc, before):
-            d = g() - b
-            if d:
-                self.deltas.append(((g, s_), d))
-        if len(acc2) != len(acc):
+        # a counter that did not exist before the capture (a lazily built clock, an optimizer or BatchNorm layer constructed inside
+        # the step) has no known per-step increment
+        if any(k not in acc for k in _counters()):
             raise RuntimeError("CapturedStep: host-side counters appeared during the capture (an optimizer or BatchNorm layer was "
                                "built inside the step, or the warm-up was too short for a lazily created clock); raise `warmup`")
+        self.deltas = []
+        for k, (g, s_) in acc.items():
+            d = g() - before[k]
+            if d:
+                self.deltas.append(((g, s_), d))
         torch.cuda.synchronize(self.device)

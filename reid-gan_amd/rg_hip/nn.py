@@ -790,26 +790,28 @@ class SNConv2d(RGModule):
         return m
 
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
-        w_sn, sigma = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training, self.eps)
+        keep_uv = tape.record and tape.wants(self.weight_orig)
+        u = v = None
+        if keep_uv:
+            w_sn, sigma, u, v = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training,
+                                                      self.eps, save_uv=True)
+        else:
+            w_sn, sigma = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training, self.eps)
         self.weight = w_sn
         f8 = self.__dict__.get("_rg_f8")
         if f8 is not None:
             from . import lowp
-            keep_uv = tape.record and tape.wants(self.weight_orig)
             xq, xq_t = f8.quant_act_both(x, keep_uv)
             wq, wq_t = f8.weights(w_sn, None)                      # W / sigma changes with every power iteration
             geom = (x.shape[0], x.shape[1], x.shape[2], x.shape[3], w_sn.shape[0], self.kernel_size[0], self.kernel_size[1],
                     self.stride[0], self.stride[1], self.padding[0], self.padding[1])
             y = lowp.conv_fwd(xq, wq, geom, shift=self.bias, residual=residual, act=act, slope=slope)
-            tape.push((xq_t, y if act != ACT_NONE else None, act, slope, w_sn, (wq_t, geom), sigma,
-                       self.weight_u.clone() if keep_uv else None, self.weight_v.clone() if keep_uv else None))
+            tape.push((xq_t, y if act != ACT_NONE else None, act, slope, w_sn, (wq_t, geom), sigma, u, v))
             return y
         wk = ops.weights_to_krsc(w_sn) if (w_sn.shape[2] * w_sn.shape[3] > 1 and w_sn.shape[1] % 4 == 0) else None
         y = ops.conv2d_fwd(x, w_sn, self.stride, self.padding, shift=self.bias, residual=residual, act=act, slope=slope,
                            w_krsc=wk)
-        keep_uv = tape.record and tape.wants(self.weight_orig)
-        tape.push((x, y if act != ACT_NONE else None, act, slope, w_sn, wk, sigma,
-                   self.weight_u.clone() if keep_uv else None, self.weight_v.clone() if keep_uv else None))
+        tape.push((x, y if act != ACT_NONE else None, act, slope, w_sn, wk, sigma, u, v))
         return y
 
     def tb(self, tape, dy, need_dx=True, residual=None):

@@ -277,6 +277,14 @@ def _nchw(x):
     return N, C, x.numel() // (N * C)
 
 
+def _same_size(what, ref, **others):
+    """element-wise operands must cover the same elements: the C ABI takes one length, so a mismatch (e.g. a residual branch with
+    another stride, as in the reference's ResNet-18 wrapper) would read out of bounds instead of failing like torch does"""
+    for name, t in others.items():
+        if t is not None and t.numel() != ref.numel():
+            raise RuntimeError("%s: the size of tensor %s %s must match %s" % (what, name, tuple(t.shape), tuple(ref.shape)))
+
+
 def bn_stats(x, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     x = _chk(x, "x")
     N, C, HW = _nchw(x)
@@ -291,6 +299,7 @@ def bn_stats(x, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
 def bn_apply_fwd(x, mean, stat, gamma, beta, residual=None, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0):
     x = _chk(x, "x")
     residual = _chk(residual, "residual")
+    _same_size("bn_apply_fwd", x, residual=residual)
     N, C, HW = _nchw(x)
     y = torch.empty_like(x)
     lib.rg_bn_apply_fwd(_p(x), _p(mean), _p(stat), _p(gamma), _p(beta), _p(residual), _p(y), N, C, HW,
@@ -301,6 +310,7 @@ def bn_apply_fwd(x, mean, stat, gamma, beta, residual=None, stat_is_var=False, e
 def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT_NONE, slope=0.0,
                   out_sum_dy=None, out_sum_dy_xhat=None):
     x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("bn_bwd_reduce", x, dy=dy, y=y_act)
     N, C, HW = _nchw(x)
     sum_dy = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     sum_dy_xhat = out_sum_dy_xhat if out_sum_dy_xhat is not None else \
@@ -325,6 +335,7 @@ def rows_sum_pair(a, b, N, C, out_a=None, out_b=None):
 def bn_bwd_apply(x, dy, y_act, mean, stat, gamma, sum_dy, sum_dy_xhat, train, stat_is_var=False, eps=1e-5,
                  act=ACT_NONE, slope=0.0, need_dx=True, need_dres=False):
     x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("bn_bwd_apply", dy, x=x, y=y_act)
     N, C, HW = _nchw(dy)
     dx = torch.empty_like(dy) if need_dx else None
     dres = torch.empty_like(dy) if need_dres else None
@@ -337,6 +348,7 @@ def bn_eval_bwd(x, dy, y_act, running_mean, running_var, gamma, eps=1e-5, act=AC
                 need_dres=False, need_sums=True, out_sum_dy=None, out_sum_dy_xhat=None):
     """Eval-mode BatchNorm backward in one pass -> (dx, dres, sum_dy, sum_dy_xhat)."""
     x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("bn_eval_bwd", dy, x=x, y=y_act)
     N, C, HW = _nchw(dy)
     dx = torch.empty_like(dy) if need_dx else None
     dres = torch.empty_like(dy) if need_dres else None
@@ -362,6 +374,7 @@ def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
 def act_bwd_sum(dy, y_act, act, slope=0.0, need_g=True, need_sum=True, out_sum=None):
     """g = dy * act'(y) and its per-channel sums over N, HW -> (g, sum_g)."""
     dy, y_act = _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("act_bwd_sum", dy, y=y_act)
     N, C, HW = _nchw(dy)
     g = torch.empty_like(dy) if need_g else None
     sg = None
@@ -386,6 +399,7 @@ def bn_fold_wgrad(w, g, scale, invstd, running_mean, sum_g, dgamma=None, partial
 def act_bwd_partial(dy, y_act, act, slope=0.0, need_g=True):
     """g = dy * act'(y) (or None) and the slice partials [C, S] of its channel sums (no finalize launch)."""
     dy, y_act = _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("act_bwd_partial", dy, y=y_act)
     N, C, HW = _nchw(dy)
     g = torch.empty_like(dy) if need_g else None
     S = _ws_query("rg_bn_slices", N, C, HW)
@@ -439,6 +453,7 @@ def act_fwd(x, act, slope=0.0, out=None):
 
 def act_bwd(dy, y, act, slope=0.0):
     dy, y = _chk(dy, "dy"), _chk(y, "y")
+    _same_size("act_bwd", dy, y=y)
     dx = torch.empty_like(dy)
     lib.rg_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, slope, _stream())
     return dx
@@ -446,6 +461,7 @@ def act_bwd(dy, y, act, slope=0.0):
 
 def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     a, b = _chk(a, "a"), _chk(b, "b")
+    _same_size("axpby", a, b=b, out=out)
     y = out if out is not None else torch.empty_like(a)
     lib.rg_axpby(_p(a), _p(b), _p(y), a.numel(), alpha, beta, _stream())
     return y
@@ -591,8 +607,9 @@ def reflection_pad2d_bwd(dy, pad):
     return dx
 
 
-def spectral_norm_fwd(w, u, v, training=True, eps=1e-12):
-    """One power iteration in place on u, v (training) and W / sigma; returns (w_sn, sigma[2] = (sigma, 1/sigma))."""
+def spectral_norm_fwd(w, u, v, training=True, eps=1e-12, save_uv=False):
+    """One power iteration in place on u, v (training) and W / sigma; returns (w_sn, sigma[2] = (sigma, 1/sigma)) and, with
+    `save_uv`, private copies of the u, v this forward used (written by the same launch)."""
     w = _chk(w, "w")
     K = w.shape[0]
     M = w.numel() // K
@@ -600,7 +617,10 @@ def spectral_norm_fwd(w, u, v, training=True, eps=1e-12):
         raise ValueError("spectral_norm: u / v do not match the weight matrix %d x %d" % (K, M))
     w_sn = torch.empty_like(w)
     sigma = torch.empty(2, dtype=torch.float32, device=w.device)
-    lib.rg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(w_sn), _p(sigma), K, M, int(bool(training)), eps, _stream())
+    saved = torch.empty(K + M, dtype=torch.float32, device=w.device) if save_uv else None
+    lib.rg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(w_sn), _p(sigma), _p(saved), K, M, int(bool(training)), eps, _stream())
+    if save_uv:
+        return w_sn, sigma, saved[:K], saved[K:]
     return w_sn, sigma
 
 

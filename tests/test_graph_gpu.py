@@ -14,13 +14,15 @@ pytestmark = pytest.mark.gpu
 def test_cluster_contrast_step_graph_and_bn_counters(dev):
     from rg_hip import optim as roptim
     from rg_hip.graph import CapturedStep
-    import clustercontrast.models as M
+    import reid.models as RM
     from clustercontrast.models.cm import ClusterMemory
     from clustercontrast.trainers import ClusterContrastTrainer
 
     def run(graph):
         torch.manual_seed(0)
-        enc = M.create('resnet18', pretrained=False, pooling_type="gem").to(dev).train()
+        # (the cluster-contrast wrapper's layer4 stride edit only fits Bottleneck depths — tests/test_cc_gpu.py — so the shallow
+        # encoder is the FD-GAN ReID wrapper; the trainer takes any encoder)
+        enc = RM.create('resnet18', pretrained=False).to(dev).train()
         mem = ClusterMemory(enc.num_features, 32, temp=0.05, momentum=0.1).to(dev)
         g = torch.Generator(device=dev).manual_seed(1)
         mem.features = F.normalize(torch.randn(32, enc.num_features, generator=g, device=dev), dim=1)
@@ -46,7 +48,8 @@ def test_cluster_contrast_step_graph_and_bn_counters(dev):
     assert torch.equal(mem_e.features, mem_g.features)
     for (n, p), (_, q) in zip(enc_e.state_dict().items(), enc_g.state_dict().items()):
         assert torch.equal(p, q), n                       # includes num_batches_tracked == 5 on both sides
-    assert int(enc_g.state_dict()["base.1.num_batches_tracked"]) == 5
+    counters = [k for k in enc_g.state_dict() if k.endswith("num_batches_tracked")]
+    assert counters and all(int(enc_g.state_dict()[k]) == 5 for k in counters)
 
 
 def test_dropout_mask_changes_between_replays(dev):

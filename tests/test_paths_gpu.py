@@ -96,12 +96,14 @@ class _Loader(object):
 
 
 def _cc_parts(dev, B, K=64):
+    """shallow encoder + memory + per-tensor Adam on both sides (the FD-GAN ReID wrapper: the cluster-contrast wrapper's
+    layer4 stride edit does not fit BasicBlock depths, neither here nor in the reference — see the test below)"""
     from rg_hip import optim as roptim
-    import clustercontrast.models as M
+    import reid.models as RM
     from clustercontrast.models.cm import ClusterMemory
     torch.manual_seed(0)
-    oenc = O.OCCResNet(18, pooling_type="gem")
-    enc = M.create('resnet18', pretrained=False, pooling_type="gem")
+    oenc = O.OReidResNet(18)
+    enc = RM.create('resnet18', pretrained=False)
     enc.load_state_dict(oenc.state_dict())
     enc = enc.to(dev)
     bank = F.normalize(torch.randn(K, enc.num_features), dim=1)
@@ -112,6 +114,22 @@ def _cc_parts(dev, B, K=64):
     opt = roptim.Adam([{"params": [p]} for p in enc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
     oopt = torch.optim.Adam([{"params": [p]} for p in oenc.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
     return enc, mem, opt, oenc, omem, oopt
+
+
+def test_basicblock_depth_in_cluster_contrast_wrapper_fails_like_the_reference(dev):
+    """CC/clustercontrast/models/resnet.py:34-35 sets layer4[0].conv2 and the downsample conv to stride 1; in a BasicBlock the
+    strided conv is conv1, so the two branches of layer4[0] disagree in size and the reference dies in the residual add
+    (RuntimeError: the size of tensor a must match ...).  Same failure here, raised on the host before any kernel reads past
+    a buffer."""
+    import clustercontrast.models as M
+    enc = M.create('resnet18', pretrained=False, pooling_type="gem").to(dev)
+    x = torch.randn(2, 3, 64, 32, device=dev)
+    for mode in ("train", "eval"):
+        getattr(enc, mode)()
+        with pytest.raises((RuntimeError, ValueError), match="(?i)size|shape"):
+            enc(x)
+    with pytest.raises(RuntimeError, match="(?i)size"):
+        O.OCCResNet(18, pooling_type="gem").train()(torch.randn(2, 3, 64, 32))
 
 
 def test_cluster_contrast_trainer_train_loop(dev, capsys):
@@ -134,7 +152,6 @@ def test_cluster_contrast_trainer_train_loop(dev, capsys):
     assert out.count("Epoch: [0][") == 3 and "Loss" in out
     oenc.train()
     ref = [O.o_cc_step(oenc, omem, oopt, it[0], it[2]) for it in items]
-    got = [float(x) for x in out.replace("(", " ").split("Loss")[1:]] if False else None
     # the printed running value of the last iteration is the third loss
     last = float(out.strip().splitlines()[-1].split("Loss")[1].split()[0])
     assert abs(last - ref[2]) <= 2e-2 * abs(ref[2]) + 1e-3, (last, ref)
