@@ -106,6 +106,15 @@ int rg_bn_apply_fwd(const float* x, const float* mean, const float* stat, const 
 int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
                      float* sum_dy, float* sum_dy_xhat, int N, int C, int HW, int stat_is_var, float eps, int act,
                      float slope, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+/* torch.nn.InstanceNorm2d (affine or not; FD/fdgan/networks.py:30, CC/dual_gan/models/base_function.py:38-49) in one launch per
+ * direction: forward writes y = act(gamma[c] * xhat + beta[c] + residual) and the per-instance mean / invstd [N*C]; backward
+ * writes dx, dres (either may be NULL), the per-instance sums of g = dy*act'(y) and g*xhat [N*C] and, when sum_dx is given, the
+ * per-instance sums of dx (the bias gradient of the convolution in front of the norm). */
+int rg_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                    float* invstd, int N, int C, int HW, float eps, int act, float slope, rg_stream_t stream);
+int rg_instnorm_bwd(const float* x, const float* dy, const float* y_act, const float* mean, const float* invstd,
+                    const float* gamma, float* dx, float* dres, float* sum_dy, float* sum_dy_xhat, float* sum_dx, int N, int C,
+                    int HW, int act, float slope, rg_stream_t stream);
 /* out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c]: dgamma / dbeta of an affine InstanceNorm2d (torch.nn.InstanceNorm2d
  * backward as used by CC/dual_gan/models/base_function.py:38-49) from the per-(n,c) sums of rg_bn_bwd_reduce. */
 int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C, rg_stream_t stream);
@@ -260,8 +269,10 @@ int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int
  * K <= 1024, M <= 12288.  Backward: dw (+)= (dw_sn - (sum dw_sn * w_sn) u v^T) / sigma with the forward's u, v. */
 int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* uv_saved, int K, int M,
                          int training, float eps, rg_stream_t stream);
+size_t rg_spectral_norm_bwd_workspace(int K, int M);
 int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
-                         float* dw, int K, int M, int accumulate, rg_stream_t stream);
+                         float* dw, int K, int M, int accumulate, void* workspace, size_t workspace_bytes,
+                         rg_stream_t stream);
 /* Batched strided fp32 GEMM (MFMA) for nn.MultiheadAttention inside CAB / TTB, PTM.py:162-247:
  * C[b0][b1][m][n] = alpha * sum_k A[b0][b1][m][k] B[b0][b1][k][n] + beta * C; all strides in elements, so Q^T K,
  * P V and the backward products run on [B][C][L] token maps without permutes. */

@@ -952,7 +952,7 @@ struct ThinP {
     FastDiv d_pq, d_q;
 };
 
-template <int KH, int KW>
+template <int KH, int KW, int KO>
 __global__ __launch_bounds__(256) void conv_fwd_k1_kernel(const ThinP t) {
     const int Ng = t.N * t.P * t.Q;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -974,40 +974,53 @@ __global__ __launch_bounds__(256) void conv_fwd_k1_kernel(const ThinP t) {
     const int c0 = blockIdx.y * t.per_slice;
     const int c1 = min(c0 + t.per_slice, t.C);
     const unsigned cstride = (unsigned)(t.H * t.W) * 4u;
-    float acc = 0.f;
+    float acc[KO];
+#pragma unroll
+    for (int k = 0; k < KO; ++k) acc[k] = 0.f;
 #pragma unroll 2
     for (int c = c0; c < c1; ++c) {
-        const float* wc = t.a + c * (KH * KW);          // uniform: scalar loads
+        const float* wc = t.a + c * (KH * KW);          // uniform: scalar loads; output channel k at + k*C*KH*KW
         const unsigned co = (unsigned)c * cstride;      // an out-of-range offset stays out of range
 #pragma unroll
         for (int r = 0; r < KH; ++r)
 #pragma unroll
-            for (int s = 0; s < KW; ++s) acc += bload(rx, off[r][s] + co) * wc[r * KW + s];
+            for (int s = 0; s < KW; ++s) {
+                const float xv = bload(rx, off[r][s] + co);
+#pragma unroll
+                for (int k = 0; k < KO; ++k) acc[k] += xv * wc[k * t.C * (KH * KW) + r * KW + s];
+            }
     }
-    t.partial[(int64_t)blockIdx.y * Ng + pix] = acc;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) t.partial[((int64_t)blockIdx.y * KO + k) * Ng + pix] = acc[k];
 }
 
-// grid (C, slices): block (c, s) reduces pixels [s*per_slice, (s+1)*per_slice) for the KH*KW taps of channel c
-template <int KH, int KW>
+// grid (C, slices): block (c, s) reduces pixels [s*per_slice, (s+1)*per_slice) for the KH*KW taps of channel c and the KO
+// output channels; partial layout [slice][KO][C][KH*KW]
+template <int KH, int KW, int KO>
 __global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const ThinP t) {
     constexpr int RS = KH * KW;
-    __shared__ float red[4][RS];
+    __shared__ float red[4][KO * RS];
     const int Ng = t.N * t.P * t.Q;
+    const int PQ = t.P * t.Q;
     const int c = blockIdx.x;
     const int beg = blockIdx.y * t.per_slice;
     const int end = min(beg + t.per_slice, Ng);
     const rsrc_t rx = make_rsrc(t.x, t.x_bytes);
-    float acc[KH][KW];
+    float acc[KO][KH][KW];
 #pragma unroll
-    for (int r = 0; r < KH; ++r)
+    for (int k = 0; k < KO; ++k)
 #pragma unroll
-        for (int s = 0; s < KW; ++s) acc[r][s] = 0.f;
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) acc[k][r][s] = 0.f;
     for (int pix = beg + threadIdx.x; pix < end; pix += 256) {
         const int img = fdiv(pix, t.d_pq);
-        const int pq = pix - img * t.P * t.Q;
+        const int pq = pix - img * PQ;
         const int pp = fdiv(pq, t.d_q), qq = pq - pp * t.Q;
         const int h0 = pp * t.SH - t.PH, w0 = qq * t.SW - t.PW;
-        const float g = t.a[pix];
+        float g[KO];
+#pragma unroll
+        for (int k = 0; k < KO; ++k) g[k] = t.a[(img * KO + k) * PQ + pq];
         const int base = (img * t.C + c) * t.H;
 #pragma unroll
         for (int r = 0; r < KH; ++r)
@@ -1015,21 +1028,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const ThinP t) {
             for (int s = 0; s < KW; ++s) {
                 const int h = h0 + r, w = w0 + s;
                 const bool ok = (unsigned)h < (unsigned)t.H && (unsigned)w < (unsigned)t.W;
-                acc[r][s] += g * bload(rx, ok ? (unsigned)((base + h) * t.W + w) * 4u : OOB);
+                const float xv = bload(rx, ok ? (unsigned)((base + h) * t.W + w) * 4u : OOB);
+#pragma unroll
+                for (int k = 0; k < KO; ++k) acc[k][r][s] += g[k] * xv;
             }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-    for (int r = 0; r < KH; ++r)
+    for (int k = 0; k < KO; ++k)
 #pragma unroll
-        for (int s = 0; s < KW; ++s) {
-            const float v = rg_wave_sum(acc[r][s]);
-            if (lane == 0) red[wid][r * KW + s] = v;
-        }
+        for (int r = 0; r < KH; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                const float v = rg_wave_sum(acc[k][r][s]);
+                if (lane == 0) red[wid][(k * KH + r) * KW + s] = v;
+            }
     __syncthreads();
-    if (threadIdx.x < RS)
-        t.partial[((int64_t)blockIdx.y * t.C + c) * RS + threadIdx.x] =
+    if (threadIdx.x < KO * RS) {
+        const int k = threadIdx.x / RS, tap = threadIdx.x - k * RS;
+        t.partial[(((int64_t)blockIdx.y * KO + k) * t.C + c) * RS + tap] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
 }
 
 // out[(img*M + m)*PIX + pix] = act((sum_s partial[s][m][n]) * scale[m] + shift[m] + res), n = img*PIX + pix
@@ -1456,11 +1475,19 @@ static unsigned finish_grid(int64_t n) {
     }
 
 namespace {
-// one-output-channel layers (conv_fwd_k1_kernel / conv_wgrad_k1_kernel): filter sizes with an instantiation
+// layers with <= 4 output channels (conv_fwd_k1_kernel / conv_wgrad_k1_kernel): filter sizes with an instantiation
 static bool thin_filter(int K, int KH, int KW) {
     static const int env = getenv("RG_THIN_CONV") ? atoi(getenv("RG_THIN_CONV")) : 1;
-    return env && K == 1 && ((KH == 4 && KW == 4) || (KH == 3 && KW == 3));
+    return env && K >= 1 && K <= 4 && ((KH == 4 && KW == 4 && K == 1) || (KH == 3 && KW == 3));
 }
+#define THIN_DISPATCH(KERNEL, grid, stream, t)                                                       \
+    do {                                                                                              \
+        if (KH == 4) hipLaunchKernelGGL((KERNEL<4, 4, 1>), grid, dim3(256), 0, stream, t);            \
+        else if (K == 1) hipLaunchKernelGGL((KERNEL<3, 3, 1>), grid, dim3(256), 0, stream, t);        \
+        else if (K == 2) hipLaunchKernelGGL((KERNEL<3, 3, 2>), grid, dim3(256), 0, stream, t);        \
+        else if (K == 3) hipLaunchKernelGGL((KERNEL<3, 3, 3>), grid, dim3(256), 0, stream, t);        \
+        else hipLaunchKernelGGL((KERNEL<3, 3, 4>), grid, dim3(256), 0, stream, t);                    \
+    } while (0)
 // forward: channels per slice so that ~2048 workgroups exist (>= 4 channels each)
 static int thin_fwd_per_slice(int C, int64_t Ng) {
     int64_t slices = rg::cdiv64(2048, rg::cdiv64(Ng, 256));
@@ -1489,7 +1516,7 @@ static void thin_fill(ThinP& t, const float* x, const float* a, float* partial, 
 extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
     if (thin_filter(K, KH, KW)) {
         const int64_t Ng = (int64_t)N * P * Q;
-        return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)Ng * sizeof(float);
+        return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)K * (size_t)Ng * sizeof(float);
     }
     const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
     return pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
@@ -1514,17 +1541,16 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     if (thin_filter(K, KH, KW)) {
         const int per = thin_fwd_per_slice(C, p.Ng);
         const int slices = rg::cdiv(C, per);
-        const size_t need = (size_t)slices * (size_t)p.Ng * sizeof(float);
+        const size_t need = (size_t)slices * (size_t)K * (size_t)p.Ng * sizeof(float);
         if (workspace && need <= workspace_bytes) {
             ThinP t;
             thin_fill(t, x, w, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
-            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * (double)p.Ng * p.Kg, ALG_BYTES);
+            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * (double)K * p.Ng * p.Kg, ALG_BYTES);
             const dim3 grid(rg::cdiv(p.Ng, 256), slices);
-            if (KH == 4) hipLaunchKernelGGL((conv_fwd_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
-            else hipLaunchKernelGGL((conv_fwd_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
+            THIN_DISPATCH(conv_fwd_k1_kernel, grid, stream, t);
             if (int e = rg::check_launch("rg_conv2d_fwd(thin)")) return e;
-            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.Ng)), dim3(256), 0, stream,
-                               t.partial, y, 1, p.Ng, P * Q, p.d_pq, slices, p.ep);
+            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)K * p.Ng)), dim3(256), 0, stream,
+                               t.partial, y, K, p.Ng, P * Q, p.d_pq, slices, p.ep);
             return rg::check_launch("rg_conv2d_fwd(thin finish)");
         }
     }
@@ -1774,7 +1800,7 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
 extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
     if (thin_filter(K, KH, KW)) {
         const int64_t Ng = (int64_t)N * P * Q;
-        return (size_t)rg::cdiv64(Ng, thin_wgrad_per_slice(C, Ng)) * (size_t)C * KH * KW * sizeof(float);
+        return (size_t)rg::cdiv64(Ng, thin_wgrad_per_slice(C, Ng)) * (size_t)K * (size_t)C * KH * KW * sizeof(float);
     }
     const WgradPlan pl = plan_wgrad(K, C * KH * KW, (int64_t)N * P * Q);
     return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
@@ -1794,16 +1820,15 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     if (thin_filter(K, KH, KW)) {
         const int per = thin_wgrad_per_slice(C, p.Kg);
         const int slices = rg::cdiv(p.Kg, per);
-        const size_t need_thin = (size_t)slices * (size_t)p.Ng * sizeof(float);
+        const size_t need_thin = (size_t)slices * (size_t)K * (size_t)p.Ng * sizeof(float);
         if (workspace && need_thin <= workspace_bytes) {
             ThinP t;
             thin_fill(t, x, dy, static_cast<float*>(workspace), N, C, H, W, SH, SW, PH, PW, P, Q, per);
-            rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * (double)p.Ng * p.Kg, ALG_BYTES);
+            rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * (double)K * p.Ng * p.Kg, ALG_BYTES);
             const dim3 grid(C, slices);
-            if (KH == 4) hipLaunchKernelGGL((conv_wgrad_k1_kernel<4, 4>), grid, dim3(256), 0, stream, t);
-            else hipLaunchKernelGGL((conv_wgrad_k1_kernel<3, 3>), grid, dim3(256), 0, stream, t);
+            THIN_DISPATCH(conv_wgrad_k1_kernel, grid, stream, t);
             if (int e = rg::check_launch("rg_conv2d_wgrad(thin)")) return e;
-            const int64_t n = (int64_t)p.Ng;
+            const int64_t n = (int64_t)K * p.Ng;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
                                static_cast<const float*>(workspace), dw, n, slices, 0, C, KH * KW);
             return rg::check_launch("rg_conv2d_wgrad(thin reduce)");

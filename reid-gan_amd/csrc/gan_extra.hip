@@ -53,36 +53,45 @@ __device__ __forceinline__ int reflect(int t, int len) {
     return t;
 }
 
-__global__ void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int pad, int OH,
-                                       int OW, int64_t total) {
-    RG_GRID_STRIDE(i, total) {
-        const int ow = (int)(i % OW);
-        const int64_t r = i / OW;
-        const int oh = (int)(r % OH);
-        const int64_t nc = r / OH;
-        y[i] = x[(nc * H + reflect(oh - pad, H)) * W + reflect(ow - pad, W)];
+// rows of 64-wide lanes: threadIdx.y walks the (plane, row) pairs with 32-bit arithmetic (one division per row, none per element)
+constexpr int PAD_ROWS = 32;                 // rows per workgroup (4 at a time)
+
+__global__ __launch_bounds__(256) void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                              int pad, int OH, int OW, int rows) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < PAD_ROWS; j += 4) {
+        const int r = blockIdx.x * PAD_ROWS + j;
+        if (r >= rows) return;
+        const int nc = r / OH, oh = r - nc * OH;
+        const float* src = x + ((int64_t)nc * H + reflect(oh - pad, H)) * W;
+        float* dst = y + (int64_t)r * OW;
+        for (int ow = tx; ow < OW; ow += 64) dst[ow] = src[reflect(ow - pad, W)];
     }
 }
 
 // gather form of the adjoint: input (h, w) collects its own copy plus the mirrored border copies
-__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int pad, int OH,
-                                       int OW, int64_t total) {
-    RG_GRID_STRIDE(i, total) {
-        const int w = (int)(i % W);
-        const int64_t r = i / W;
-        const int h = (int)(r % H);
-        const int64_t nc = r / H;
-        int hs[3], ws[3], nh = 0, nw = 0;
+__global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                                              int pad, int OH, int OW, int rows) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < PAD_ROWS; j += 4) {
+        const int r = blockIdx.x * PAD_ROWS + j;
+        if (r >= rows) return;
+        const int nc = r / H, h = r - nc * H;
+        int hs[3], nh = 0;
         hs[nh++] = h + pad;
         if (h >= 1 && h <= pad) hs[nh++] = pad - h;
         if (h <= H - 2 && h >= H - 1 - pad) hs[nh++] = pad + 2 * (H - 1) - h;
-        ws[nw++] = w + pad;
-        if (w >= 1 && w <= pad) ws[nw++] = pad - w;
-        if (w <= W - 2 && w >= W - 1 - pad) ws[nw++] = pad + 2 * (W - 1) - w;
-        float s = 0.f;
-        for (int a = 0; a < nh; ++a)
-            for (int b = 0; b < nw; ++b) s += dy[(nc * OH + hs[a]) * OW + ws[b]];
-        dx[i] = s;
+        const float* base = dy + (int64_t)nc * OH * OW;
+        for (int w = tx; w < W; w += 64) {
+            int ws[3], nw = 0;
+            ws[nw++] = w + pad;
+            if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+            if (w <= W - 2 && w >= W - 1 - pad) ws[nw++] = pad + 2 * (W - 1) - w;
+            float s = 0.f;
+            for (int a = 0; a < nh; ++a)
+                for (int b = 0; b < nw; ++b) s += base[hs[a] * OW + ws[b]];
+            dx[(int64_t)r * W + w] = s;
+        }
     }
 }
 
@@ -213,7 +222,9 @@ extern "C" int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, i
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * OH * OW;
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, total);
+    RG_REQUIRE((int64_t)N * C * OH < (1ll << 31), "rg_reflection_pad2d_fwd: N*C*OH exceeds 2^31");
+    const int rows = N * C * OH;
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(rg::cdiv(rows, PAD_ROWS)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, rows);
     return rg::check_launch("rg_reflection_pad2d_fwd");
 }
 
@@ -222,7 +233,9 @@ extern "C" int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C,
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * H * W;
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, total);
+    RG_REQUIRE((int64_t)N * C * OH < (1ll << 31), "rg_reflection_pad2d_bwd: N*C*OH exceeds 2^31");
+    const int rows = N * C * H;
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(rg::cdiv(rows, PAD_ROWS)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, rows);
     return rg::check_launch("rg_reflection_pad2d_bwd");
 }
 
@@ -239,10 +252,62 @@ extern "C" int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w
     return rg::check_launch("rg_spectral_norm_fwd");
 }
 
+namespace {
+// larger filters: the dot product as slice partials (one workgroup per slice), then an element-wise pass in which every
+// workgroup adds the SN_SLICES partials in the same order — two parallel launches instead of one serial workgroup
+constexpr int SN_SLICES = 64;
+constexpr int SN_SINGLE_MAX = 16384;      // up to here the one-workgroup kernel (a single launch) is faster
+
+__global__ __launch_bounds__(256) void spectral_norm_dot_partial_kernel(const float* __restrict__ dwsn,
+                                                                       const float* __restrict__ wsn, float* __restrict__ part,
+                                                                       int64_t n) {
+    __shared__ float red[16];
+    const int64_t per = (n + SN_SLICES - 1) / SN_SLICES;
+    const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float s = 0.f;
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += dwsn[i] * wsn[i];
+    s = rg_block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void spectral_norm_bwd_apply_kernel(const float* __restrict__ dwsn, const float* __restrict__ part,
+                                                                     const float* __restrict__ u, const float* __restrict__ v,
+                                                                     const float* __restrict__ sigma, float* __restrict__ dw,
+                                                                     int K, int M, int accumulate) {
+    float c = 0.f;
+    for (int i = 0; i < SN_SLICES; ++i) c += part[i];              // uniform: scalar loads, same order in every workgroup
+    const float inv = sigma[1];
+    const int64_t n = (int64_t)K * M;
+    RG_GRID_STRIDE(i, n) {
+        const int k = (int)(i / M), m = (int)(i - (int64_t)k * M);
+        const float g = (dwsn[i] - c * u[k] * v[m]) * inv;
+        dw[i] = accumulate ? dw[i] + g : g;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t rg_spectral_norm_bwd_workspace(int K, int M) {
+    return (int64_t)K * M > SN_SINGLE_MAX ? SN_SLICES * sizeof(float) : 0;
+}
+
 extern "C" int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
-                                    float* dw, int K, int M, int accumulate, hipStream_t stream) {
+                                    float* dw, int K, int M, int accumulate, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
     RG_REQUIRE(dw_sn && w_sn && u && v && sigma && dw && K > 0 && M > 0, "rg_spectral_norm_bwd: bad arguments");
     rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, 16.0 * K * M);
+    const int64_t n = (int64_t)K * M;
+    if (n > SN_SINGLE_MAX) {
+        if (!workspace || workspace_bytes < SN_SLICES * sizeof(float)) {
+            rg::set_error("rg_spectral_norm_bwd: workspace too small");
+            return RG_ERR_WORKSPACE;
+        }
+        float* part = static_cast<float*>(workspace);
+        hipLaunchKernelGGL(spectral_norm_dot_partial_kernel, dim3(SN_SLICES), dim3(256), 0, stream, dw_sn, w_sn, part, n);
+        hipLaunchKernelGGL(spectral_norm_bwd_apply_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dw_sn, part, u, v, sigma, dw,
+                           K, M, accumulate);
+        return rg::check_launch("rg_spectral_norm_bwd");
+    }
     hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(SN_THREADS), 0, stream, dw_sn, w_sn, u, v, sigma, dw, K, M,
                        accumulate);
     return rg::check_launch("rg_spectral_norm_bwd");

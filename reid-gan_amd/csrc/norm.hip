@@ -619,27 +619,255 @@ extern "C" int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_
     return rg::check_launch("rg_bn_bwd_reduce");
 }
 
-// out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c] (ascending n): the affine gradients of an InstanceNorm from the per-(n,c) sums
-// its backward reduction already produced.  Either pair may be NULL.
-__global__ void rows_sum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ oa,
-                                     float* __restrict__ ob, int N, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float sa = 0.f, sb = 0.f;
-    for (int n = 0; n < N; ++n) {
-        if (a) sa += a[(int64_t)n * C + c];
-        if (b) sb += b[(int64_t)n * C + c];
+// ---- InstanceNorm2d in one launch per direction -----------------------------------------------------------------------
+// An instance (n, c) is HW contiguous floats: <= 32 KB for every map of the dual_gan / FD-GAN networks, so the second and third
+// pass over it hit L1 / L2.  WAVES = 1: one wave per instance (4 instances per workgroup, shuffles only) for small maps;
+// WAVES = 4: one workgroup per instance.  Statistics: mean, then the centred sum of squares (two-pass, biased variance).
+template <int WAVES>
+__device__ __forceinline__ float in_reduce(float v, float* red) {
+    v = rg_wave_sum(v);
+    if (WAVES == 1) return v;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ res,
+                                                           float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ invstd_out, int NC, int C, int HW, float eps,
+                                                           int act, float slope) {
+    __shared__ float red[4];
+    const int inst = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (inst >= NC) return;                                   // WAVES == 1 only (whole waves leave; no barrier in that mode)
+    const int t = WAVES == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    constexpr int T = WAVES * 64;
+    const int64_t base = (int64_t)inst * HW;
+    const float* xp = x + base;
+    const bool vec = (HW & 3) == 0;
+    const int nv = HW >> 2;
+    float s = 0.f;
+    if (vec) {
+        for (int i = t; i < nv; i += T) {
+            const float4 v = reinterpret_cast<const float4*>(xp)[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = t; i < HW; i += T) s += xp[i];
     }
-    if (a) oa[c] = sa;
-    if (b) ob[c] = sb;
+    const float mu = in_reduce<WAVES>(s, red) / (float)HW;
+    float q = 0.f;
+    if (vec) {
+        for (int i = t; i < nv; i += T) {
+            const float4 v = reinterpret_cast<const float4*>(xp)[i];
+            const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    } else {
+        for (int i = t; i < HW; i += T) {
+            const float a = xp[i] - mu;
+            q += a * a;
+        }
+    }
+    const float is = rsqrtf(in_reduce<WAVES>(q, red) / (float)HW + eps);
+    if (t == 0) {
+        mean_out[inst] = mu;
+        invstd_out[inst] = is;
+    }
+    const int c = inst % C;
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float sh = (beta ? beta[c] : 0.f) - mu * gs;
+    float* yp = y + base;
+    const float* rp = res ? res + base : nullptr;
+    if (vec) {
+        for (int i = t; i < nv; i += T) {
+            const float4 v = reinterpret_cast<const float4*>(xp)[i];
+            float4 o;
+            o.x = v.x * gs + sh; o.y = v.y * gs + sh; o.z = v.z * gs + sh; o.w = v.w * gs + sh;
+            if (rp) {
+                const float4 r = reinterpret_cast<const float4*>(rp)[i];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            o.x = rg_apply_act(o.x, act, slope); o.y = rg_apply_act(o.y, act, slope);
+            o.z = rg_apply_act(o.z, act, slope); o.w = rg_apply_act(o.w, act, slope);
+            reinterpret_cast<float4*>(yp)[i] = o;
+        }
+    } else {
+        for (int i = t; i < HW; i += T) {
+            float o = xp[i] * gs + sh;
+            if (rp) o += rp[i];
+            yp[i] = rg_apply_act(o, act, slope);
+        }
+    }
+}
+
+// g = dy * act'(y); s1 = sum g, s2 = sum g * xhat (written per instance for the affine gradients);
+// dx = gamma * invstd * (g - s1 / HW - xhat * s2 / HW); dres = g
+template <int WAVES>
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ yact, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           float* __restrict__ dx, float* __restrict__ dres,
+                                                           float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
+                                                           float* __restrict__ sum_dx, int NC, int C, int HW, int act,
+                                                           float slope) {
+    __shared__ float red[4];
+    const int inst = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (inst >= NC) return;
+    const int t = WAVES == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    constexpr int T = WAVES * 64;
+    const int64_t base = (int64_t)inst * HW;
+    const float* xp = x + base;
+    const float* gp = dy + base;
+    const float* yp = act != RG_ACT_NONE ? yact + base : nullptr;
+    const float mu = mean[inst], is = invstd[inst];
+    const bool vec = (HW & 3) == 0;
+    const int nv = HW >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    if (vec) {
+        for (int i = t; i < nv; i += T) {
+            float4 g = reinterpret_cast<const float4*>(gp)[i];
+            if (yp) {
+                const float4 yv = reinterpret_cast<const float4*>(yp)[i];
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            const float4 v = reinterpret_cast<const float4*>(xp)[i];
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * (v.x - mu) + g.y * (v.y - mu)) + (g.z * (v.z - mu) + g.w * (v.w - mu));
+        }
+    } else {
+        for (int i = t; i < HW; i += T) {
+            float g = gp[i];
+            if (yp) g *= act_grad_from_out(yp[i], act, slope);
+            s1 += g;
+            s2 += g * (xp[i] - mu);
+        }
+    }
+    s1 = in_reduce<WAVES>(s1, red);
+    s2 = in_reduce<WAVES>(s2, red) * is;
+    if (t == 0) {
+        sum_dy[inst] = s1;
+        sum_dy_xhat[inst] = s2;
+    }
+    const float gs = (gamma ? gamma[inst % C] : 1.f) * is;
+    const float a = s1 / (float)HW, b = s2 / (float)HW * is;
+    float* dxp = dx ? dx + base : nullptr;
+    float* drp = dres ? dres + base : nullptr;
+    float sdx = 0.f;
+    if (vec) {
+        for (int i = t; i < nv; i += T) {
+            float4 g = reinterpret_cast<const float4*>(gp)[i];
+            if (yp) {
+                const float4 yv = reinterpret_cast<const float4*>(yp)[i];
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (drp) reinterpret_cast<float4*>(drp)[i] = g;
+            if (dxp) {
+                const float4 v = reinterpret_cast<const float4*>(xp)[i];
+                float4 o;
+                o.x = gs * (g.x - a - (v.x - mu) * b); o.y = gs * (g.y - a - (v.y - mu) * b);
+                o.z = gs * (g.z - a - (v.z - mu) * b); o.w = gs * (g.w - a - (v.w - mu) * b);
+                reinterpret_cast<float4*>(dxp)[i] = o;
+                sdx += (o.x + o.y) + (o.z + o.w);
+            }
+        }
+    } else {
+        for (int i = t; i < HW; i += T) {
+            float g = gp[i];
+            if (yp) g *= act_grad_from_out(yp[i], act, slope);
+            if (drp) drp[i] = g;
+            if (dxp) {
+                const float o = gs * (g - a - (xp[i] - mu) * b);
+                dxp[i] = o;
+                sdx += o;
+            }
+        }
+    }
+    if (sum_dx) {                                                // uniform: the bias gradient of the convolution in front
+        sdx = in_reduce<WAVES>(sdx, red);
+        if (t == 0) sum_dx[inst] = sdx;
+    }
+}
+
+// out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c] (fixed summation order): the affine gradients of an InstanceNorm from the per-(n,c) sums
+// its backward reduction already produced.  Either pair may be NULL.
+__global__ __launch_bounds__(256) void rows_sum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ oa, float* __restrict__ ob, int N, int C) {
+    // 16 channels x 16 row lanes per workgroup: lane ny sums rows ny, ny + 16, ...; the 16 lane sums are added in lane order
+    __shared__ float sa[16][17], sb[16][17];
+    const int cx = threadIdx.x & 15, ny = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    float x = 0.f, y = 0.f;
+    if (c < C) {
+        for (int n = ny; n < N; n += 16) {
+            if (a) x += a[(int64_t)n * C + c];
+            if (b) y += b[(int64_t)n * C + c];
+        }
+    }
+    sa[ny][cx] = x;
+    sb[ny][cx] = y;
+    __syncthreads();
+    if (ny == 0 && c < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ta += sa[i][cx];
+            tb += sb[i][cx];
+        }
+        if (a) oa[c] = ta;
+        if (b) ob[c] = tb;
+    }
 }
 
 extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C,
                                 hipStream_t stream) {
     RG_REQUIRE((a || b) && (!a || out_a) && (!b || out_b) && N > 0 && C > 0, "rg_rows_sum_pair: bad arguments");
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * ((a ? 1 : 0) + (b ? 1 : 0)) * (double)(N + 1) * C);
-    hipLaunchKernelGGL(rows_sum_pair_kernel, dim3(rg::cdiv(C, 64)), dim3(64), 0, stream, a, b, out_a, out_b, N, C);
+    hipLaunchKernelGGL(rows_sum_pair_kernel, dim3(rg::cdiv(C, 16)), dim3(256), 0, stream, a, b, out_a, out_b, N, C);
     return rg::check_launch("rg_rows_sum_pair");
+}
+
+// InstanceNorm2d forward: y = act(gamma[c] * (x - mean[n,c]) * invstd[n,c] + beta[c] + residual); mean / invstd [N*C] are kept for
+// the backward.  One launch.
+extern "C" int rg_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                               float* mean, float* invstd, int N, int C, int HW, float eps, int act, float slope,
+                               hipStream_t stream) {
+    RG_REQUIRE(x && y && mean && invstd && N > 0 && C > 0 && HW > 0, "rg_instnorm_fwd: bad arguments");
+    RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_fwd: N*C exceeds 2^31");
+    const int NC = N * C;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * (double)NC * HW);
+    if (HW <= 2048)
+        hipLaunchKernelGGL(instnorm_fwd_kernel<1>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, gamma, beta, residual, y, mean,
+                           invstd, NC, C, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(NC), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd, NC,
+                           C, HW, eps, act, slope);
+    return rg::check_launch("rg_instnorm_fwd");
+}
+
+// InstanceNorm2d backward in one launch: dx, dres (either may be NULL) and the per-instance sums [N*C] of g = dy*act'(y) and
+// g*xhat (dbeta / dgamma = their sums over n: rg_rows_sum_pair); sum_dx (may be NULL) receives the per-instance sums of dx — the
+// bias gradient of a convolution that feeds this layer, without another pass over dx.
+extern "C" int rg_instnorm_bwd(const float* x, const float* dy, const float* y_act, const float* mean, const float* invstd,
+                               const float* gamma, float* dx, float* dres, float* sum_dy, float* sum_dy_xhat, float* sum_dx, int N,
+                               int C, int HW, int act, float slope, hipStream_t stream) {
+    RG_REQUIRE(x && dy && mean && invstd && sum_dy && sum_dy_xhat && N > 0 && C > 0 && HW > 0, "rg_instnorm_bwd: bad arguments");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_instnorm_bwd: fused activation needs the forward output");
+    RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_bwd: N*C exceeds 2^31");
+    const int NC = N * C;
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, ((act ? 12.0 : 8.0) + (dx ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)) * (double)NC * HW);
+    if (HW <= 2048)
+        hipLaunchKernelGGL(instnorm_bwd_kernel<1>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma,
+                           dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope);
+    else
+        hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(NC), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres,
+                           sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope);
+    return rg::check_launch("rg_instnorm_bwd");
 }
 
 // dx (may be NULL) and dres (may be NULL; the gradient of a fused residual input = dy*act'(y)).

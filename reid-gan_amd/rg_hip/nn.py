@@ -28,6 +28,18 @@ WEIGHT_EPOCH = [0]      # bumped by rg_hip.optim after every step (its kernels b
 BN_LAYERS = weakref.WeakSet()      # rg_hip.graph advances their host-side `num_batches_tracked` bookkeeping per replay
 
 
+def _bias_grad(tape, bias, dy):
+    """sum of dy over N and the pixels.  When dy is the tensor an InstanceNorm backward just produced, that kernel already
+    summed it per (n, c): one tiny launch over [N][C] instead of another pass over the activation."""
+    part = getattr(dy, "_rg_inst_sums", None)
+    N, C = dy.shape[0], dy.shape[1]
+    if part is not None and part.numel() == N * C:
+        db, _ = ops.rows_sum_pair(part, None, N, C, tape.grad_out(bias), None)
+    else:
+        db = ops.channel_sum(dy, out=tape.grad_out(bias))
+    tape.add_grad(bias, db)
+
+
 class _KrscCache(object):
     """[K][KH*KW][C] copy of a filter tensor for the (r,s)-major kernels, rebuilt only when the weights changed."""
 
@@ -118,7 +130,7 @@ class Conv2d(RGModule, _KrscCache):
             if want_w:
                 tape.add_grad(self.weight, lowp.conv_wgrad(xq_t, dyq_t, geom, out=tape.grad_out(self.weight)))
             if tape.wants(self.bias):
-                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             _, wq_t = f8.weights(self.weight.detach(), self._wkey())
@@ -130,7 +142,7 @@ class Conv2d(RGModule, _KrscCache):
             tape.add_grad(self.weight, ops.conv2d_wgrad(x, dy, self.weight.shape, self.stride, self.padding,
                                                         out=tape.grad_out(self.weight), side=True))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            _bias_grad(tape, self.bias, dy)
         if not need_dx:
             return None
         if self._full_extent(x) and dx_channels is None and residual is None and not mask_input and not want_rowsum:
@@ -217,7 +229,7 @@ class ConvTranspose2d(RGModule, _KrscCache):
                 # filter gradient with the roles swapped: the "input" is dy (e5m2), the "output gradient" is x (e4m3)
                 tape.add_grad(self.weight, lowp.conv_wgrad(dyq_t, xq_t, geom, out=tape.grad_out(self.weight)))
             if tape.wants(self.bias):
-                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             wq, _ = f8.weights(self.weight.detach(), self._wkey())
@@ -229,7 +241,7 @@ class ConvTranspose2d(RGModule, _KrscCache):
             tape.add_grad(self.weight, ops.conv2d_wgrad(dy, x, self.weight.shape, self.stride, self.padding,
                                                         out=tape.grad_out(self.weight), side=True))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            _bias_grad(tape, self.bias, dy)
         if not need_dx:
             return None
         if (x.shape[2] == 1 and x.shape[3] == 1 and self.padding == (0, 0) and self.output_padding == (0, 0)
@@ -263,7 +275,7 @@ class Linear(RGModule):
         if tape.wants(self.weight):
             tape.add_grad(self.weight, ops.linear_wgrad(x, dy, out=tape.grad_out(self.weight)))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            _bias_grad(tape, self.bias, dy)
         return ops.linear_dgrad(dy, self.weight) if need_dx else None
 
 
@@ -662,9 +674,9 @@ class Sequential(RGModule):
 
 
 class InstanceNorm2d(RGModule):
-    """Instance norm == batch norm over a [1][N*C][HW] view with batch statistics (no running stats),
-    so it runs on the same kernels.  affine=False is the FD-GAN setting (FD/fdgan/networks.py:30);
-    affine=True (dual_gan, CC/dual_gan/models/base_function.py:38-48) tiles gamma/beta over N."""
+    """One launch per direction (`rg_instnorm_fwd` / `rg_instnorm_bwd`): statistics, affine map, residual add and activation in the
+    forward; activation gradient, both per-instance sums, dx and the residual gradient in the backward.  affine=False is the
+    FD-GAN setting (FD/fdgan/networks.py:30); affine=True dual_gan's (CC/dual_gan/models/base_function.py:38-48)."""
 
     def __init__(self, num_features, eps=1e-5, affine=False):
         super(InstanceNorm2d, self).__init__()
@@ -676,39 +688,23 @@ class InstanceNorm2d(RGModule):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
-    def _tiled_affine(self, N):
-        """gamma / beta repeated per sample (the kernels see N*C channels), rebuilt only when the parameters changed"""
-        w = self.weight
-        arena = getattr(w, "_rg_arena", None)
-        key = (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, self.bias._version, w.data_ptr(), N)
-        if self.__dict__.get("_tiled_key") != key:
-            self.__dict__["_tiled"] = (w.detach().repeat(N), self.bias.detach().repeat(N))
-            self.__dict__["_tiled_key"] = key
-        return self.__dict__["_tiled"]
-
     def tf(self, tape, x, residual=None, act=ACT_NONE, slope=0.0):
-        N, C = x.shape[0], x.shape[1]
-        xv = x.reshape(1, N * C, *x.shape[2:])
-        mean, invstd = ops.bn_stats(xv, None, None, self.eps, 0.0)
-        g, b = self._tiled_affine(N) if self.affine else (None, None)
-        rv = residual.reshape(xv.shape) if residual is not None else None
-        y = ops.bn_apply_fwd(xv, mean, invstd, g, b, rv, False, self.eps, act, slope)
-        tape.push((xv, y if act != ACT_NONE else None, mean, invstd, g, act, slope, residual is not None, x.shape))
-        return y.view(x.shape)
+        g = self.weight.detach() if self.affine else None
+        b = self.bias.detach() if self.affine else None
+        y, mean, invstd = ops.instnorm_fwd(x, g, b, residual, self.eps, act, slope)
+        tape.push((x, y if act != ACT_NONE else None, mean, invstd, g, act, slope, residual is not None))
+        return y
 
     def tb(self, tape, dy, need_dx=True):
-        xv, y, mean, invstd, g, act, slope, has_res, shape = tape.pop()
-        N, C = shape[0], shape[1]
-        dyv = dy.reshape(xv.shape)
-        s1, s2 = ops.bn_bwd_reduce(xv, dyv, y, mean, invstd, False, self.eps, act, slope)
+        x, y, mean, invstd, g, act, slope, has_res = tape.pop()
+        N, C = x.shape[0], x.shape[1]
+        dx, dres, s1, s2, s3 = ops.instnorm_bwd(x, dy, y, mean, invstd, g, act, slope, need_dx=True, need_dres=has_res)
         if self.affine and tape.wants(self.weight):
             dg, db = ops.rows_sum_pair(s2, s1, N, C, tape.grad_out(self.weight), tape.grad_out(self.bias))
             tape.add_grad(self.weight, dg)
             tape.add_grad(self.bias, db)
-        dx, dres = ops.bn_bwd_apply(xv, dyv, y, mean, invstd, g, s1, s2, True, False, self.eps, act, slope,
-                                    need_dx=True, need_dres=has_res)
-        dx = dx.view(shape)
-        return (dx, dres.view(shape)) if has_res else dx
+        dx._rg_inst_sums = s3           # per-(n, c) sums of dx: the bias gradient of a convolution in front (see _bias_grad)
+        return (dx, dres) if has_res else dx
 
 
 class InstanceNorm1d(InstanceNorm2d):
@@ -829,7 +825,7 @@ class SNConv2d(RGModule):
                 tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,
                                                                       out=tape.grad_out(self.weight_orig)))
             if tape.wants(self.bias):
-                tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             return lowp.conv_dgrad(dyq, wq_t, geom, (geom[2], geom[3]), residual=residual)
@@ -838,7 +834,7 @@ class SNConv2d(RGModule):
             tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,
                                                                   out=tape.grad_out(self.weight_orig)))
         if tape.wants(self.bias):
-            tape.add_grad(self.bias, ops.channel_sum(dy, out=tape.grad_out(self.bias)))
+            _bias_grad(tape, self.bias, dy)
         if not need_dx:
             return None
         return ops.conv2d_dgrad(dy, w_sn, x.shape[2:], self.stride, self.padding, residual=residual, w_krsc=wk)

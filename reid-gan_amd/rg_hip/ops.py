@@ -321,6 +321,31 @@ def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT
     return sum_dy, sum_dy_xhat
 
 
+def instnorm_fwd(x, gamma=None, beta=None, residual=None, eps=1e-5, act=ACT_NONE, slope=0.0):
+    """InstanceNorm over the trailing dims of x[N][C][...] in one launch -> (y, mean[N*C], invstd[N*C])."""
+    x, residual = _chk(x, "x"), _chk(residual, "residual")
+    _same_size("instnorm_fwd", x, residual=residual)
+    N, C, HW = _nchw(x)
+    y = torch.empty_like(x)
+    stats = torch.empty(2, N * C, dtype=torch.float32, device=x.device)
+    lib.rg_instnorm_fwd(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats[0]), _p(stats[1]), N, C, HW, eps, act, slope,
+                        _stream())
+    return y, stats[0], stats[1]
+
+
+def instnorm_bwd(x, dy, y_act, mean, invstd, gamma=None, act=ACT_NONE, slope=0.0, need_dx=True, need_dres=False):
+    """-> (dx, dres, sum_g[N*C], sum_g_xhat[N*C], sum_dx[N*C]) in one launch."""
+    x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("instnorm_bwd", dy, x=x, y=y_act)
+    N, C, HW = _nchw(x)
+    dx = torch.empty_like(dy) if need_dx else None
+    dres = torch.empty_like(dy) if need_dres else None
+    sums = torch.empty(3, N * C, dtype=torch.float32, device=x.device)
+    lib.rg_instnorm_bwd(_p(x), _p(dy), _p(y_act), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dres), _p(sums[0]), _p(sums[1]),
+                        _p(sums[2]) if need_dx else None, N, C, HW, act, slope, _stream())
+    return dx, dres, sums[0], sums[1], (sums[2] if need_dx else None)
+
+
 def rows_sum_pair(a, b, N, C, out_a=None, out_b=None):
     """column sums of two [N][C] matrices in one launch (InstanceNorm affine gradients)."""
     dev = (a if a is not None else b).device
@@ -463,6 +488,8 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     a, b = _chk(a, "a"), _chk(b, "b")
     _same_size("axpby", a, b=b, out=out)
     y = out if out is not None else torch.empty_like(a)
+    if out is not None and getattr(out, "_rg_inst_sums", None) is not None:
+        out._rg_inst_sums = None        # accumulating into an InstanceNorm's dx invalidates the sums that kernel attached to it
     lib.rg_axpby(_p(a), _p(b), _p(y), a.numel(), alpha, beta, _stream())
     return y
 
@@ -629,7 +656,10 @@ def spectral_norm_bwd(dw_sn, w_sn, u, v, sigma, out=None, accumulate=False):
     K = w_sn.shape[0]
     M = w_sn.numel() // K
     dw = out if out is not None else torch.empty_like(w_sn)
-    lib.rg_spectral_norm_bwd(_p(dw_sn), _p(w_sn), _p(u), _p(v), _p(sigma), _p(dw), K, M, int(accumulate), _stream())
+    need = _ws_query("rg_spectral_norm_bwd_workspace", K, M)
+    ws = workspace(need, w_sn.device) if need else None
+    lib.rg_spectral_norm_bwd(_p(dw_sn), _p(w_sn), _p(u), _p(v), _p(sigma), _p(dw), K, M, int(accumulate), _p(ws),
+                             ws.numel() if ws is not None else 0, _stream())
     return dw
 
 

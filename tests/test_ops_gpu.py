@@ -59,6 +59,9 @@ CONV_CASES = [
     (2, 4, 10, 6, 6, 3, 3, 2, 1),        # C = 4: one-pixel-per-thread kernel
     (3, 40, 9, 7, 1, 3, 3, 2, 1),        # one output channel, 3x3 / 2 (direct kernels, channel / pixel slices)
     (5, 130, 20, 12, 1, 4, 4, 1, 1),     # one output channel, ragged channel slices
+    (3, 64, 18, 10, 3, 3, 3, 1, 0),      # dual_gan Output conv: 64 -> 3 on the reflection-padded map (direct kernels, 3 channels)
+    (2, 37, 11, 9, 2, 3, 3, 2, 1),       # 2 output channels, stride 2, ragged slices
+    (2, 130, 12, 8, 4, 3, 3, 1, 1),      # 4 output channels
 ]
 
 
@@ -101,6 +104,18 @@ def test_conv_fused_epilogue(dev):
         y = ops.conv2d_fwd(x.to(dev), w.to(dev), 1, 1, scale=sc.to(dev), shift=sh.to(dev), residual=res.to(dev), act=act,
                            slope=0.2)
         _close(y, fn(ref), name="epilogue act=%d" % act)
+
+
+def test_thin_conv_fused_epilogue(dev):
+    """<= 4 output channels: the direct kernels' slice partials go through the split-K finishing kernel, which owns the epilogue"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 64, 14, 10, generator=g)
+    w = torch.randn(3, 64, 3, 3, generator=g) * 0.05
+    b = torch.randn(3, generator=g)
+    ref = torch.tanh(F.conv2d(x.double(), w.double(), b.double()))
+    y = ops.conv2d_fwd(x.to(dev), w.to(dev), 1, 0, shift=b.to(dev), act=ops.ACT_TANH)
+    _close(y, ref, name="thin conv + bias + tanh")
 
 
 @pytest.mark.parametrize("case", [
@@ -430,6 +445,13 @@ def test_avgpool_reflection_pad(dev):
         yr.backward(dy.double())
         _close(ops.reflection_pad2d_fwd(x.to(dev), pad), yr, name="reflect fwd")
         _close(ops.reflection_pad2d_bwd(dy.to(dev), pad), xr.grad, name="reflect bwd")
+    x3 = torch.randn(2, 3, 37, 70, generator=g)         # rows wider than one 64-lane pass, row count not a multiple of 32
+    xr = x3.double().requires_grad_(True)
+    yr = F.pad(xr, (1,) * 4, mode="reflect")
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    _close(ops.reflection_pad2d_fwd(x3.to(dev), 1), yr, name="reflect fwd wide")
+    _close(ops.reflection_pad2d_bwd(dy.to(dev), 1), xr.grad, name="reflect bwd wide")
 
 
 @pytest.mark.parametrize("shape", [(32, 3, 3, 3), (64, 32, 4, 4), (1, 128, 1, 1), (128, 128, 4, 4)])
@@ -459,9 +481,17 @@ def test_spectral_norm(dev, shape):
     ref.eval()                                            # eval: no iteration, same u / v
     ref(x)
     u2, v2 = u.clone(), v.clone()
-    w_sn2, _ = ops.spectral_norm_fwd(wd, u2, v2, False)
+    w_sn2, _, us, vs = ops.spectral_norm_fwd(wd, u2, v2, False, save_uv=True)
     _close(w_sn2, ref.weight, tol=1e-5, name="w_sn eval")
     assert torch.equal(u2, u) and torch.equal(v2, v)
+    assert torch.equal(us, u) and torch.equal(vs, v)       # the copies the backward keeps
+    # a training forward saves the u, v it produced; accumulate adds into an existing gradient
+    u3, v3 = u.clone(), v.clone()
+    w_sn3, sigma3, us3, vs3 = ops.spectral_norm_fwd(wd, u3, v3, True, save_uv=True)
+    assert torch.equal(us3, u3) and torch.equal(vs3, v3)
+    acc = dw.clone()
+    ops.spectral_norm_bwd(gw.float().to(dev), w_sn, u, v, sigma, out=acc, accumulate=True)
+    _close(acc, 2 * ref.weight_orig.grad, tol=1e-5, name="dw accumulate")
 
 
 def test_bgemm_and_softmax(dev):
@@ -612,3 +642,43 @@ def test_dgrad_rowsum(dev, case):
         return
     assert part is not None and tuple(part.shape) == (C, cols)
     _close(part.sum(1), dx.double().sum((0, 2, 3)), tol=2e-5, name="row sums")
+
+
+@pytest.mark.parametrize("shape,affine,act", [((3, 5, 7, 9), True, "leaky"),        # 63 elements: one wave per instance, scalar loads
+                                              ((2, 16, 32, 16), True, "none"),      # 512: one wave, float4
+                                              ((2, 6, 64, 48), True, "relu"),       # 3072: one workgroup per instance, float4
+                                              ((2, 3, 51, 43), False, "none"),      # 2193: one workgroup, scalar loads
+                                              ((4, 8, 1, 50), False, "leaky")])     # token maps [B, C, L]
+def test_instance_norm_single_launch(dev, shape, affine, act):
+    """rg_instnorm_fwd / rg_instnorm_bwd against torch's instance_norm in fp64: output, statistics, dx, residual gradient, the
+    per-instance sums behind dgamma / dbeta, and the per-instance sums of dx (bias gradient of the convolution in front)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    N, C = shape[:2]
+    x = torch.randn(shape, generator=g) * 1.7 + 0.3
+    res = torch.randn(shape, generator=g)
+    gam = (torch.rand(C, generator=g) + 0.5) if affine else None
+    bet = torch.randn(C, generator=g) if affine else None
+    a, slope = {"none": (ops.ACT_NONE, 0.0), "relu": (ops.ACT_RELU, 0.0), "leaky": (ops.ACT_LEAKY, 0.1)}[act]
+    fn = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.1)}[act]
+    xd, rd = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gd = gam.double().requires_grad_(True) if affine else None
+    bd = bet.double().requires_grad_(True) if affine else None
+    yref = fn(F.instance_norm(xd, weight=gd, bias=bd, eps=1e-5) + rd)
+    dy = torch.randn(shape, generator=g)
+    yref.backward(dy.double())
+    y, mean, invstd = ops.instnorm_fwd(x.to(dev), gam.to(dev) if affine else None, bet.to(dev) if affine else None, res.to(dev), 1e-5,
+                                       a, slope)
+    _close(y, yref, name="y")
+    _close(mean.view(N, C), x.double().flatten(2).mean(2), name="mean")
+    dx, dres, s1, s2, s3 = ops.instnorm_bwd(x.to(dev), dy.to(dev), y, mean, invstd, gam.to(dev) if affine else None, a, slope,
+                                            need_dx=True, need_dres=True)
+    _close(dx, xd.grad, tol=5e-5, name="dx")
+    _close(dres, rd.grad, name="dres")
+    if affine:
+        dg, db = ops.rows_sum_pair(s2, s1, N, C)
+        _close(dg, gd.grad, tol=5e-5, name="dgamma")
+        _close(db, bd.grad, tol=5e-5, name="dbeta")
+    # sums of dx per instance: compare with the sums of the kernel's own dx (mathematically ~0, numerically noise)
+    ref3 = dx.double().flatten(2).sum(2).flatten()
+    assert (s3.double() - ref3).abs().max().item() <= 1e-4 * max(dx.abs().max().item(), 1e-6) * dx[0, 0].numel() ** 0.5
