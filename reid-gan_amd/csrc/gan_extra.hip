@@ -53,45 +53,53 @@ __device__ __forceinline__ int reflect(int t, int len) {
     return t;
 }
 
-// rows of 64-wide lanes: threadIdx.y walks the (plane, row) pairs with 32-bit arithmetic (one division per row, none per element)
-constexpr int PAD_ROWS = 32;                 // rows per workgroup (4 at a time)
+// one thread per element, 32-bit index arithmetic with multiply-high divisions by the two row lengths (the 64-bit `/` and `%` of a
+// generic grid-stride loop cost more than the copy itself)
+struct PadDiv {
+    unsigned mul, shr, d;
+};
+static PadDiv make_paddiv(unsigned d) {
+    PadDiv f;
+    f.d = d ? d : 1;
+    f.mul = 0;
+    f.shr = 0;
+    if (f.d == 1) return f;
+    unsigned l = 0;
+    while ((1ull << l) < f.d) ++l;
+    const unsigned p = 31 + l;
+    f.mul = (unsigned)(((1ull << p) + f.d - 1) / f.d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ int pdiv(int n, const PadDiv& f) { return f.d == 1 ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.shr); }
 
 __global__ __launch_bounds__(256) void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
-                                                              int pad, int OH, int OW, int rows) {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int j = ty; j < PAD_ROWS; j += 4) {
-        const int r = blockIdx.x * PAD_ROWS + j;
-        if (r >= rows) return;
-        const int nc = r / OH, oh = r - nc * OH;
-        const float* src = x + ((int64_t)nc * H + reflect(oh - pad, H)) * W;
-        float* dst = y + (int64_t)r * OW;
-        for (int ow = tx; ow < OW; ow += 64) dst[ow] = src[reflect(ow - pad, W)];
+                                                              int pad, int OH, int OW, int total, PadDiv d_ow, PadDiv d_oh) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = pdiv(i, d_ow), ow = i - r * OW;
+        const int nc = pdiv(r, d_oh), oh = r - nc * OH;
+        y[i] = x[((int64_t)nc * H + reflect(oh - pad, H)) * W + reflect(ow - pad, W)];
     }
 }
 
 // gather form of the adjoint: input (h, w) collects its own copy plus the mirrored border copies
 __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
-                                                              int pad, int OH, int OW, int rows) {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int j = ty; j < PAD_ROWS; j += 4) {
-        const int r = blockIdx.x * PAD_ROWS + j;
-        if (r >= rows) return;
-        const int nc = r / H, h = r - nc * H;
-        int hs[3], nh = 0;
+                                                              int pad, int OH, int OW, int total, PadDiv d_w, PadDiv d_h) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = pdiv(i, d_w), w = i - r * W;
+        const int nc = pdiv(r, d_h), h = r - nc * H;
+        int hs[3], ws[3], nh = 0, nw = 0;
         hs[nh++] = h + pad;
         if (h >= 1 && h <= pad) hs[nh++] = pad - h;
         if (h <= H - 2 && h >= H - 1 - pad) hs[nh++] = pad + 2 * (H - 1) - h;
+        ws[nw++] = w + pad;
+        if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+        if (w <= W - 2 && w >= W - 1 - pad) ws[nw++] = pad + 2 * (W - 1) - w;
         const float* base = dy + (int64_t)nc * OH * OW;
-        for (int w = tx; w < W; w += 64) {
-            int ws[3], nw = 0;
-            ws[nw++] = w + pad;
-            if (w >= 1 && w <= pad) ws[nw++] = pad - w;
-            if (w <= W - 2 && w >= W - 1 - pad) ws[nw++] = pad + 2 * (W - 1) - w;
-            float s = 0.f;
-            for (int a = 0; a < nh; ++a)
-                for (int b = 0; b < nw; ++b) s += base[hs[a] * OW + ws[b]];
-            dx[(int64_t)r * W + w] = s;
-        }
+        float s = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) s += base[hs[a] * OW + ws[b]];
+        dx[i] = s;
     }
 }
 
@@ -222,9 +230,9 @@ extern "C" int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, i
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * OH * OW;
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    RG_REQUIRE((int64_t)N * C * OH < (1ll << 31), "rg_reflection_pad2d_fwd: N*C*OH exceeds 2^31");
-    const int rows = N * C * OH;
-    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(rg::cdiv(rows, PAD_ROWS)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, rows);
+    RG_REQUIRE(total < (1ll << 31) - (1 << 22), "rg_reflection_pad2d_fwd: more than 2^31 elements");
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, (int)total,
+                       make_paddiv(OW), make_paddiv(OH));
     return rg::check_launch("rg_reflection_pad2d_fwd");
 }
 
@@ -233,9 +241,9 @@ extern "C" int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C,
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * H * W;
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    RG_REQUIRE((int64_t)N * C * OH < (1ll << 31), "rg_reflection_pad2d_bwd: N*C*OH exceeds 2^31");
-    const int rows = N * C * H;
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(rg::cdiv(rows, PAD_ROWS)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, rows);
+    RG_REQUIRE((int64_t)N * C * OH * OW < (1ll << 31) - (1 << 22), "rg_reflection_pad2d_bwd: more than 2^31 elements");
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, (int)total,
+                       make_paddiv(W), make_paddiv(H));
     return rg::check_launch("rg_reflection_pad2d_bwd");
 }
 

@@ -403,6 +403,91 @@ __global__ __launch_bounds__(NT) void gemm_v7(const float* At, const float* B, f
     store_c(C, N, m0, n0, wm, wn, lane, acc);
 }
 
+// ---- v8: EIGHT waves per workgroup on the same 128x128xBK tile: wave group g = wid >> 2 runs the MFMA k-steps of half g of every
+// LDS tile (same LDS traffic and global loads per tile as v0, half the staging work per thread, TWO waves per SIMD at one
+// workgroup per CU), the two partial accumulators are added through LDS at the end.  BK8 = 16 or 32. --------------------------
+template <int BK8>
+__global__ __launch_bounds__(512) void gemm_v8(const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int LD = 132, T = 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];            // max(staging 2*2*BK8*LD, reduction 128*LD) floats
+    float (*As)[BK8][LD] = reinterpret_cast<float (*)[BK8][LD]>(smem);
+    float (*Bs)[BK8][LD] = reinterpret_cast<float (*)[BK8][LD]>(smem + 2 * BK8 * LD);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, grp = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+    const int m0 = (blockIdx.x % (M / BM)) * BM, n0 = (blockIdx.x / (M / BM)) * BN;
+    floatx16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int NV = BK8 / 16;                   // float4 per thread, operand and tile (128*BK8/4 / 512)
+    float4 ra[NV], rb[NV];
+    auto ld = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + T * i;
+            const int row = v / (BK8 / 4), kq = (v % (BK8 / 4)) * 4;
+            ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + row) * K + k0 + kq);
+            const int kk = v / 32, nq = (v % 32) * 4;
+            rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(k0 + kk) * N + n0 + nq);
+        }
+    };
+    auto st = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + T * i;
+            const int row = v / (BK8 / 4), kq = (v % (BK8 / 4)) * 4;
+            As[buf][kq + 0][row] = ra[i].x; As[buf][kq + 1][row] = ra[i].y; As[buf][kq + 2][row] = ra[i].z; As[buf][kq + 3][row] = ra[i].w;
+            const int kk = v / 32, nq = (v % 32) * 4;
+            *reinterpret_cast<float4*>(&Bs[buf][kk][nq]) = rb[i];
+        }
+    };
+    ld(0);
+    st(0);
+    __syncthreads();
+    const int nk = K / BK8;
+    const int l32 = lane & 31, kh = lane >> 5;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) ld((kt + 1) * BK8);
+#pragma unroll
+        for (int ks = 0; ks < BK8 / 4; ++ks) {      // this group's half of the tile's k-steps
+            const int k = grp * (BK8 / 2) + 2 * ks + kh;
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[cur][k][wm * 64 + i * 32 + l32];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[cur][k][wn * 64 + j * 32 + l32];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (has_next && ks == BK8 / 4 - 1) st(cur ^ 1);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // group 1 hands its partial tile over through LDS (aliases the staging buffers: every wave is past the last barrier)
+    float (*R)[LD] = reinterpret_cast<float (*)[LD]>(smem);
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    R[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh][wn * 64 + j * 32 + l32] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += R[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh][wn * 64 + j * 32 + l32];
+        store_c(C, N, m0, n0, wm, wn, lane, acc);
+    }
+}
+
 int main(int argc, char** argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const int per_cu = argc > 2 ? atoi(argv[2]) : 1;
@@ -424,6 +509,9 @@ int main(int argc, char** argv) {
     }
     const int blocks = (M / 128) * (N / 128);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 132 * 4);
+    const int v8_lds16 = 128 * 132 * 4, v8_lds32 = 128 * 132 * 4;      // reduction tile (67.6 KB) >= staging (33.8 / 67.6 KB)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v8<16>), hipFuncAttributeMaxDynamicSharedMemorySize, v8_lds16);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v8<32>), hipFuncAttributeMaxDynamicSharedMemorySize, v8_lds32);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
@@ -435,6 +523,8 @@ int main(int argc, char** argv) {
         else if (variant == 72) hipLaunchKernelGGL(gemm_v7<2>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
         else if (variant == 73) hipLaunchKernelGGL(gemm_v7<3>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
         else if (variant == 74) hipLaunchKernelGGL(gemm_v7<4>, dim3(blocks), dim3(NT), 0, 0, At, B, C, M, N, K);
+        else if (variant == 816) hipLaunchKernelGGL(gemm_v8<16>, dim3(blocks), dim3(512), v8_lds16, 0, A, B, C, M, N, K);
+        else if (variant == 832) hipLaunchKernelGGL(gemm_v8<32>, dim3(blocks), dim3(512), v8_lds32, 0, A, B, C, M, N, K);
         else if (variant == 5) hipLaunchKernelGGL(gemm_v5, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 4) hipLaunchKernelGGL(gemm_v4, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
         else if (variant == 3) hipLaunchKernelGGL(gemm_v3, dim3(blocks), dim3(NT), 0, 0, A, B, C, M, N, K);
