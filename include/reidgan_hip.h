@@ -132,6 +132,10 @@ int rg_bn_eval_bwd(const float* x, const float* dy, const float* y_act, const fl
 int rg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, rg_stream_t stream);
 int rg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope, rg_stream_t stream);
 int rg_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, rg_stream_t stream);
+/* Pair batch of FDGANModel.set_input (FD/fdgan/model.py:127-150): out[0:B] = a, out[B:2B][i] = take_a[i] ? a[i] : b[i] — the
+ * reference's `cat([x1, x1*mask + x2*(1-mask)])` with a 0/1 mask, and plain `cat([x1, x2])` for take_a == NULL.  per = floats
+ * per sample. */
+int rg_pair_cat(const float* a, const float* b, const int64_t* take_a, float* out, int B, int64_t per, rg_stream_t stream);
 int rg_fill(float* y, int64_t n, float v, rg_stream_t stream);
 /* (x1-x2)^2 of EltwiseSubEmbed, FD/reid/models/embedding.py:26-31 */
 int rg_sub_square_fwd(const float* a, const float* b, float* y, int64_t n, rg_stream_t stream);
@@ -269,6 +273,19 @@ int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int
  * K <= 1024, M <= 12288.  Backward: dw (+)= (dw_sn - (sum dw_sn * w_sn) u v^T) / sigma with the forward's u, v. */
 int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* uv_saved, int K, int M,
                          int training, float eps, rg_stream_t stream);
+/* The same for every spectral-normed filter of one network forward (ResDiscriminator: 13 filters) in two launches. */
+#define RG_SN_MAX_BATCH 16
+typedef struct rg_sn_desc {
+    const float* w;
+    float* u;
+    float* v;
+    float* w_sn;
+    float* sigma;
+    float* uv_saved;
+    int K;
+    int M;
+} rg_sn_desc;
+int rg_spectral_norm_fwd_multi(const rg_sn_desc* descs, int count, int training, float eps, rg_stream_t stream);
 size_t rg_spectral_norm_bwd_workspace(int K, int M);
 int rg_spectral_norm_bwd(const float* dw_sn, const float* w_sn, const float* u, const float* v, const float* sigma,
                          float* dw, int K, int M, int accumulate, void* workspace, size_t workspace_bytes,

@@ -199,6 +199,35 @@ extern "C" int rg_axpby(const float* a, const float* b, float* y, int64_t n, flo
     return rg::check_launch("rg_axpby");
 }
 
+// out[i] = a[i], out[B + i] = take_a[i] ? a[i] : b[i]  (i < B samples of `per` floats; take_a == NULL: always b).
+// grid (chunks, 2B): one sample row per blockIdx.y, float4 when `per` allows.
+__global__ __launch_bounds__(256) void pair_cat_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const int64_t* __restrict__ take_a, float* __restrict__ out, int B,
+                                                       int64_t per) {
+    const int row = blockIdx.y;
+    const int i = row < B ? row : row - B;
+    const float* src = (row < B || (take_a && take_a[i] != 0)) ? a + (int64_t)i * per : b + (int64_t)i * per;
+    float* dst = out + (int64_t)row * per;
+    if ((per & 3) == 0) {
+        const int64_t nv = per >> 2;
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nv; j += (int64_t)gridDim.x * 256)
+            reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(src)[j];
+    } else {
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < per; j += (int64_t)gridDim.x * 256) dst[j] = src[j];
+    }
+}
+
+extern "C" int rg_pair_cat(const float* a, const float* b, const int64_t* take_a, float* out, int B, int64_t per,
+                           hipStream_t stream) {
+    RG_REQUIRE(a && b && out && B > 0 && per > 0 && 2 * (int64_t)B <= 65535, "rg_pair_cat: bad arguments");
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 16.0 * B * (double)per);
+    int64_t chunks = rg::cdiv64((per & 3) ? per : per / 4, 256 * 4);
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(pair_cat_kernel, dim3((unsigned)chunks, 2 * B), dim3(256), 0, stream, a, b, take_a, out, B, per);
+    return rg::check_launch("rg_pair_cat");
+}
+
 extern "C" int rg_fill(float* y, int64_t n, float v, hipStream_t stream) {
     RG_REQUIRE(y && n >= 0, "rg_fill: bad arguments");
     if (n == 0) return RG_OK;

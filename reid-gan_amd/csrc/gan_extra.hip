@@ -111,14 +111,9 @@ __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __res
 constexpr int SN_THREADS = 1024;
 constexpr int SN_MAX_M = 12288;         // v (and W^T u) live in LDS
 
-__global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const float* __restrict__ w, float* __restrict__ u,
-                                                                        float* __restrict__ v, float* __restrict__ sigma_out,
-                                                                        float* __restrict__ uv_saved, int K, int M, int training,
-                                                                        float eps) {
-    __shared__ float vs[SN_MAX_M];
-    __shared__ float us[1024];
-    __shared__ float ss[1024];
-    __shared__ float red[32];
+__device__ __forceinline__ void sn_power(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ v,
+                                         float* __restrict__ sigma_out, float* __restrict__ uv_saved, int K, int M, int training,
+                                         float eps, float* vs, float* us, float* ss, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int k = tid; k < K; k += SN_THREADS) us[k] = u[k];
     __syncthreads();
@@ -177,6 +172,38 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const f
         sigma_out[0] = sigma;
         sigma_out[1] = 1.f / sigma;
     }
+}
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_kernel(const float* __restrict__ w, float* __restrict__ u,
+                                                                        float* __restrict__ v, float* __restrict__ sigma_out,
+                                                                        float* __restrict__ uv_saved, int K, int M, int training,
+                                                                        float eps) {
+    __shared__ float vs[SN_MAX_M];
+    __shared__ float us[1024];
+    __shared__ float ss[1024];
+    __shared__ float red[32];
+    sn_power(w, u, v, sigma_out, uv_saved, K, M, training, eps, vs, us, ss, red);
+}
+
+// all spectral-normed filters of one network forward in two launches: workgroup b iterates matrix b, then grid (x, b) scales it
+struct SNBatch {
+    rg_sn_desc d[RG_SN_MAX_BATCH];
+};
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_power_multi_kernel(const SNBatch batch, int training, float eps) {
+    __shared__ float vs[SN_MAX_M];
+    __shared__ float us[1024];
+    __shared__ float ss[1024];
+    __shared__ float red[32];
+    const rg_sn_desc& d = batch.d[blockIdx.x];
+    sn_power(d.w, d.u, d.v, d.sigma, d.uv_saved, d.K, d.M, training, eps, vs, us, ss, red);
+}
+
+__global__ __launch_bounds__(256) void spectral_norm_scale_multi_kernel(const SNBatch batch) {
+    const rg_sn_desc& d = batch.d[blockIdx.y];
+    const float f = d.sigma[1];
+    const int64_t n = (int64_t)d.K * d.M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d.w_sn[i] = d.w[i] * f;
 }
 
 __global__ void scale_by_device_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ s,
@@ -258,6 +285,35 @@ extern "C" int rg_spectral_norm_fwd(const float* w, float* u, float* v, float* w
     const int64_t n = (int64_t)K * M;
     hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w, w_sn, sigma + 1, n);
     return rg::check_launch("rg_spectral_norm_fwd");
+}
+
+extern "C" int rg_spectral_norm_fwd_multi(const rg_sn_desc* descs, int count, int training, float eps, hipStream_t stream) {
+    RG_REQUIRE(descs && count > 0, "rg_spectral_norm_fwd_multi: bad arguments");
+    double bytes = 0.0;
+    for (int i = 0; i < count; ++i) {
+        const rg_sn_desc& d = descs[i];
+        RG_REQUIRE(d.w && d.u && d.v && d.w_sn && d.sigma && d.K > 0 && d.M > 0, "rg_spectral_norm_fwd_multi: bad descriptor %d", i);
+        RG_REQUIRE(d.K <= 1024 && d.M <= SN_MAX_M, "rg_spectral_norm_fwd_multi: matrix %d x %d exceeds the single-workgroup limits (1024 x %d)",
+                   d.K, d.M, SN_MAX_M);
+        bytes += 12.0 * d.K * d.M;
+    }
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, bytes);
+    for (int i0 = 0; i0 < count; i0 += RG_SN_MAX_BATCH) {
+        const int nb = count - i0 < RG_SN_MAX_BATCH ? count - i0 : RG_SN_MAX_BATCH;
+        SNBatch batch;
+        int64_t nmax = 0;
+        for (int i = 0; i < nb; ++i) {
+            batch.d[i] = descs[i0 + i];
+            const int64_t n = (int64_t)batch.d[i].K * batch.d[i].M;
+            if (n > nmax) nmax = n;
+        }
+        hipLaunchKernelGGL(spectral_norm_power_multi_kernel, dim3(nb), dim3(SN_THREADS), 0, stream, batch, training, eps);
+        unsigned gx = (unsigned)rg::cdiv64(nmax, 256 * 4);
+        if (gx > 256) gx = 256;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(spectral_norm_scale_multi_kernel, dim3(gx, nb), dim3(256), 0, stream, batch);
+    }
+    return rg::check_launch("rg_spectral_norm_fwd_multi");
 }
 
 namespace {

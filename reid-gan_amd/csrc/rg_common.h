@@ -16,6 +16,19 @@
 #define RG_ERR_LAUNCH (-2)
 #define RG_ERR_WORKSPACE (-3)
 
+// mirror of include/reidgan_hip.h (the public header is C and is not included by the kernels)
+#define RG_SN_MAX_BATCH 16
+typedef struct rg_sn_desc {
+    const float* w;
+    float* u;
+    float* v;
+    float* w_sn;
+    float* sigma;
+    float* uv_saved;
+    int K;
+    int M;
+} rg_sn_desc;
+
 namespace rg {
 
 void set_error(const char* fmt, ...);

@@ -430,8 +430,15 @@ class ResDiscriminator(RGModule):
             setattr(self, 'encoder' + str(i), block)
         self.conv = SpectralNorm(rnn.Conv2d(ndf * mult, 1, 1))
 
+    def _sn_convs(self):
+        c = self.__dict__.get("_sn_list")
+        if c is None:
+            c = self.__dict__["_sn_list"] = [m for m in self.modules() if isinstance(m, rnn.SNConv2d)]
+        return c
+
     def tf(self, tape, x):
         act, slope = _slope(self.nonlinearity)
+        rnn.sn_prepare(self._sn_convs(), self.training)     # every filter of this forward: one power-iteration launch
         out = self.block0.tf(tape, x)
         for i in range(self.layers - 1):
             out = getattr(self, 'encoder' + str(i)).tf(tape, out)

@@ -169,6 +169,19 @@ class FDGANModel(object):
         if noise is None:
             noise = torch.randn(labels.size(0), self.opt.noise_feature_size, device=labels.device)
 
+        dev = self.device
+        if input1['origin'].is_cuda and input1['origin'].dtype == torch.float32:
+            # batch already on the GPU (device-side input pipeline): the pair tensors in one launch each — the 0 / 1 blend
+            # x1*mask + x2*(1 - mask) of the reference is a per-sample selection
+            self.labels = labels.to(dev, non_blocking=True).contiguous()
+            z = noise.to(dev, non_blocking=True).float()
+            self.origin = ops.pair_cat(input1['origin'], input2['origin'])
+            self.target = ops.pair_cat(input1['target'], input2['target'], self.labels)
+            self.posemap = ops.pair_cat(input1['posemap'], input2['posemap'], self.labels)
+            self.noise = ops.pair_cat(z, z)
+            return
+
+        # host batch (the reference's data loader): same expressions as the reference, then one copy per tensor
         # keep the same pose map for persons with the same identity
         mask = labels.view(-1, 1, 1, 1).expand_as(input1['posemap'])
         posemap2 = input1['posemap'] * mask.float() + input2['posemap'] * (1 - mask.float())
@@ -180,7 +193,6 @@ class FDGANModel(object):
         posemap = torch.cat([input1['posemap'], posemap2])
         noise = torch.cat((noise, noise))
 
-        dev = self.device
         self.origin = origin.to(dev, non_blocking=True).contiguous()
         self.target = target.to(dev, non_blocking=True).contiguous()
         self.posemap = posemap.to(dev, non_blocking=True).contiguous()

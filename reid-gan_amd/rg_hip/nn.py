@@ -40,6 +40,19 @@ def _bias_grad(tape, bias, dy):
     tape.add_grad(bias, db)
 
 
+def sn_prepare(convs, training):
+    """power iteration + W / sigma of every spectral-normed convolution a network forward is about to run, in two launches instead
+    of two per layer; each SNConv2d.tf picks its result up (same u / v updates, same values as the per-layer launches)"""
+    convs = [m for m in convs if isinstance(m, SNConv2d)]
+    if not convs:
+        return
+    eps = convs[0].eps
+    res = ops.spectral_norm_fwd_multi([(m.weight_orig.detach(), m.weight_u, m.weight_v) for m in convs], training, eps,
+                                      save_uv=True)
+    for m, r in zip(convs, res):
+        m.__dict__["_sn_pre"] = r
+
+
 class _KrscCache(object):
     """[K][KH*KW][C] copy of a filter tensor for the (r,s)-major kernels, rebuilt only when the weights changed."""
 
@@ -788,7 +801,10 @@ class SNConv2d(RGModule):
     def tf(self, tape, x, act=ACT_NONE, slope=0.0, residual=None):
         keep_uv = tape.record and tape.wants(self.weight_orig)
         u = v = None
-        if keep_uv:
+        pre = self.__dict__.pop("_sn_pre", None)      # (w_sn, sigma, u, v) from the network's batched launch (sn_prepare)
+        if pre is not None:
+            w_sn, sigma, u, v = pre
+        elif keep_uv:
             w_sn, sigma, u, v = ops.spectral_norm_fwd(self.weight_orig.detach(), self.weight_u, self.weight_v, self.training,
                                                       self.eps, save_uv=True)
         else:

@@ -7,6 +7,8 @@ from __future__ import absolute_import
 
 import os
 
+import ctypes
+
 import torch
 
 from .lib import lib
@@ -502,6 +504,17 @@ def scale(a, alpha):
     return axpby(a, None, alpha, 0.0)
 
 
+def pair_cat(a, b, take_a=None):
+    """[2B, ...]: rows 0..B-1 = a, rows B.. = a[i] where take_a[i] != 0 else b[i] (take_a None: b) — one launch."""
+    a, b = _chk(a, "a"), _chk(b, "b")
+    _same_size("pair_cat", a, b=b)
+    take_a = _chk(take_a, "take_a", torch.int64)
+    B = a.shape[0]
+    out = torch.empty((2 * B,) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+    lib.rg_pair_cat(_p(a), _p(b), _p(take_a), _p(out), B, a.numel() // B, _stream())
+    return out
+
+
 def fill_(t, v):
     lib.rg_fill(_p(t), t.numel(), float(v), _stream())
     return t
@@ -649,6 +662,44 @@ def spectral_norm_fwd(w, u, v, training=True, eps=1e-12, save_uv=False):
     if save_uv:
         return w_sn, sigma, saved[:K], saved[K:]
     return w_sn, sigma
+
+
+class _SNDesc(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("w_sn", ctypes.c_void_p),
+                ("sigma", ctypes.c_void_p), ("uv_saved", ctypes.c_void_p), ("K", ctypes.c_int), ("M", ctypes.c_int)]
+
+
+def spectral_norm_fwd_multi(items, training=True, eps=1e-12, save_uv=False):
+    """`items`: [(w, u, v)] of one network forward -> [(w_sn, sigma, u_saved, v_saved)] in two launches (rg_spectral_norm_fwd_multi);
+    outputs are views of one allocation."""
+    n = len(items)
+    dev = items[0][0].device
+    sizes = []
+    total = 0
+    for w, u, v in items:
+        w = _chk(w, "w")
+        K = w.shape[0]
+        M = w.numel() // K
+        if u.numel() != K or v.numel() != M or not (u.is_contiguous() and v.is_contiguous()):
+            raise ValueError("spectral_norm: u / v do not match the weight matrix %d x %d" % (K, M))
+        sizes.append((K, M, total))
+        total += (K * M + 3) // 4 * 4 + 4 + ((K + M + 3) // 4 * 4 if save_uv else 0)
+    buf = torch.empty(total, dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    descs = (_SNDesc * n)()
+    out = []
+    for i, ((w, u, v), (K, M, off)) in enumerate(zip(items, sizes)):
+        o_sig = off + (K * M + 3) // 4 * 4
+        o_uv = o_sig + 4
+        d = descs[i]
+        d.w, d.u, d.v = w.data_ptr(), u.data_ptr(), v.data_ptr()
+        d.w_sn, d.sigma = base + 4 * off, base + 4 * o_sig
+        d.uv_saved = base + 4 * o_uv if save_uv else None
+        d.K, d.M = K, M
+        out.append((buf[off:off + K * M].view(w.shape), buf[o_sig:o_sig + 2],
+                    buf[o_uv:o_uv + K] if save_uv else None, buf[o_uv + K:o_uv + K + M] if save_uv else None))
+    lib.rg_spectral_norm_fwd_multi(ctypes.addressof(descs), n, int(bool(training)), eps, _stream())
+    return out
 
 
 def spectral_norm_bwd(dw_sn, w_sn, u, v, sigma, out=None, accumulate=False):

@@ -682,3 +682,36 @@ def test_instance_norm_single_launch(dev, shape, affine, act):
     # sums of dx per instance: compare with the sums of the kernel's own dx (mathematically ~0, numerically noise)
     ref3 = dx.double().flatten(2).sum(2).flatten()
     assert (s3.double() - ref3).abs().max().item() <= 1e-4 * max(dx.abs().max().item(), 1e-6) * dx[0, 0].numel() ** 0.5
+
+
+def test_pair_cat(dev):
+    """FDGANModel.set_input's pair batch: cat([x1, x1*mask + x2*(1-mask)]) with a 0/1 mask is a per-sample selection"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    for shape in ((5, 3, 6, 4), (4, 7), (3, 18, 5, 3)):
+        a, b = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        lab = torch.randint(0, 2, (shape[0],), generator=g)
+        m = lab.view(-1, *([1] * (len(shape) - 1))).float()
+        ref = torch.cat([a, a * m + b * (1 - m)])
+        assert torch.equal(ops.pair_cat(a.to(dev), b.to(dev), lab.to(dev)).cpu(), ref)
+        assert torch.equal(ops.pair_cat(a.to(dev), b.to(dev)).cpu(), torch.cat([a, b]))
+
+
+def test_spectral_norm_multi_equals_per_layer(dev):
+    """rg_spectral_norm_fwd_multi (all filters of a discriminator forward in two launches) == the per-layer entry point bit for bit:
+    W / sigma, sigma, the in-place u / v update and the saved copies"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(32, 3, 3, 3), (64, 32, 3, 3), (1, 128, 1, 1), (128, 64, 4, 4), (5, 7, 1, 1)]
+    ws = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    us = [F.normalize(torch.randn(s[0], generator=g), dim=0).to(dev) for s in shapes]
+    vs = [F.normalize(torch.randn(s[1] * s[2] * s[3], generator=g), dim=0).to(dev) for s in shapes]
+    for training in (True, False):
+        u1, v1 = [u.clone() for u in us], [v.clone() for v in vs]
+        u2, v2 = [u.clone() for u in us], [v.clone() for v in vs]
+        single = [ops.spectral_norm_fwd(w, u, v, training, 1e-12, save_uv=True) for w, u, v in zip(ws, u1, v1)]
+        multi = ops.spectral_norm_fwd_multi(list(zip(ws, u2, v2)), training, 1e-12, save_uv=True)
+        for i, (a, b) in enumerate(zip(single, multi)):
+            for x, y, what in zip(a, b, ("w_sn", "sigma", "u saved", "v saved")):
+                assert torch.equal(x, y), (i, what, training)
+            assert torch.equal(u1[i], u2[i]) and torch.equal(v1[i], v2[i]), (i, training)

@@ -231,7 +231,8 @@ def _cm_worker(rank, world, port, q):
         # single-process reference on the global batch in rank order
         ref = _cpu_cm_update(x_all, y_all, bank0.clone(), 0.2)
         grad_ref = torch.ones(B, K) @ bank0
-        q.put((rank, (bank - ref).abs().max().item(), (xs.grad - grad_ref).abs().max().item(), bank.clone()))
+        q.put((rank, (bank - ref).abs().max().item(), (xs.grad - grad_ref).abs().max().item(), bank.numpy().tobytes()))   # bytes, not a tensor:
+        # a tensor travels as a shared-memory handle the parent must fetch while this process is still alive
     finally:
         dist.destroy_process_group()
 
@@ -250,4 +251,4 @@ def test_cluster_memory_gather_and_ordered_update_world2():
     for rank, bank_err, grad_err, _ in res:
         assert bank_err == 0.0, (rank, bank_err)      # every replica applied the same updates in the same order
         assert grad_err < 1e-6, (rank, grad_err)      # the input gradient used the PRE-update bank and stays local
-    assert torch.equal(res[0][3], res[1][3])
+    assert res[0][3] == res[1][3]

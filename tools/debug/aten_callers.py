@@ -2,8 +2,8 @@
 
     python tools/debug/aten_callers.py 5 [steps]
 
-Runs bench.py's workload for the given BASELINE configuration under torch.profiler with Python stacks and prints, per ATen
-operator that launches device work (copy_, fill_, cat, clone, contiguous, add, mul, ...), the innermost repo source lines
+Runs bench.py's workload for the given BASELINE configuration under a TorchDispatchMode that records the Python stack of every
+ATen call and prints, per ATen operator that launches device work (copy_, fill_, cat, clone, contiguous, add, mul, ...), the innermost repo source lines
 that called it with their call counts per step.  The step path is meant to be hand-written kernels only; every line listed
 here is either host bookkeeping that should not touch the device or a candidate for one of the fused kernels.
 """
@@ -28,24 +28,29 @@ def main():
     for _ in range(3):
         w.step()
     torch.cuda.synchronize()
-    from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    by_op = collections.defaultdict(collections.Counter)
+
+    class Recorder(TorchDispatchMode):
+        """every ATen call the main thread dispatches (the autograd engine's worker thread — custom Function backward bodies —
+        is outside a dispatch mode; those bodies are the tape programs, which call the C ABI directly)"""
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            where = "?"
+            for fr in reversed(traceback.extract_stack(limit=24)):
+                fn = fr.filename
+                if fn.startswith(ROOT) and "aten_callers" not in fn and "/torch/" not in fn:
+                    where = "%s:%d (%s)" % (fn.replace(ROOT + "/", ""), fr.lineno, fr.name)
+                    break
+            by_op["aten::" + func.__name__.split(".")[0]][where] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Recorder():
         for _ in range(steps):
             w.step()
         torch.cuda.synchronize()
-    by_op = collections.defaultdict(collections.Counter)
-    for ev in prof.events():
-        name = ev.name
-        if not name.startswith("aten::"):
-            continue
-        if ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
-            continue                                            # count the outermost ATen call only
-        where = "?"
-        for fr in (ev.stack or []):
-            if ROOT in fr and "/torch/" not in fr and "aten_callers" not in fr:
-                where = fr.replace(ROOT + "/", "")
-                break
-        by_op[name][where] += 1
     skip = {"aten::empty", "aten::empty_like", "aten::view", "aten::reshape", "aten::as_strided", "aten::empty_strided",
             "aten::detach", "aten::alias", "aten::slice", "aten::select", "aten::narrow", "aten::unsqueeze", "aten::squeeze",
             "aten::t", "aten::transpose", "aten::permute", "aten::expand", "aten::size", "aten::stride", "aten::is_contiguous",
