@@ -170,14 +170,26 @@ __global__ __launch_bounds__(256) void f8_quantize_transpose_kernel(const float*
 
 
 // Both operand layouts of one tensor in ONE pass over the fp32 data: in[n][c][l] -> a[n][l][cp] and b[c][l][np] (cp / np: c / n
-// padded to 16 with zero bytes).  Tile = 16 n x 16 c x 64 l: the 256 (n, c) rows are read as coalesced float4 streams, the
-// quantised bytes are transposed through a 16 KiB LDS tile, and every thread emits one 16-byte store per (n, l) for `a` and per
-// (c, l) for `b`.  grid (l tiles, c tiles, n tiles).
+// padded to 16 with zero bytes).  Tile = 16 n x 16 c x 64 l, grid (l tiles, c tiles, n tiles).  Thread (lq, c) reads, in pass n,
+// the float4 of pixels 4 lq .. 4 lq + 3 of row (n, c) (coalesced 256-byte runs) and packs it into one word of 4 fp8 bytes.
+//   layout b (n contiguous): byte j of the thread's own 16 words IS the 16-byte run b[c][4 lq + j][n0 .. n0 + 15] — assembled with
+//     byte permutes in registers, no LDS;
+//   layout a (c contiguous): the words go through a 16 KiB LDS tile [n][lq][c] (word index XOR-swizzled: conflict-free stores),
+//     thread (n, lq) reads its 16 words back with four ds_read_b128 and permutes them into the four runs a[n][4 lq + j][c0 .. c0 + 15].
+// (The first version moved single bytes through LDS: 128 ds_read_u8 per thread; this one issues 16 ds_write_b32 + 4 ds_read_b128.)
+__device__ __forceinline__ unsigned byte_of4(unsigned w0, unsigned w1, unsigned w2, unsigned w3, int j) {
+    // {w0.byte[j], w1.byte[j], w2.byte[j], w3.byte[j]}; v_perm_b32 selects from the 8 bytes of (hi : lo), selector bytes 0-3 = lo
+    const unsigned sel = (unsigned)j | ((unsigned)(4 + j) << 8);
+    const unsigned t01 = __builtin_amdgcn_perm(w1, w0, sel);          // bytes 0, 1 = w0[j], w1[j]
+    const unsigned t23 = __builtin_amdgcn_perm(w3, w2, sel);
+    return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+}
+
 __global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __restrict__ in, unsigned char* __restrict__ a,
                                                                unsigned char* __restrict__ b, float* __restrict__ state,
                                                                float* __restrict__ scale_out, int fmt, int N, int C, int L,
                                                                int Cp, int Np) {
-    __shared__ __attribute__((aligned(16))) unsigned char tile[16][16][64];     // [n][c][l]
+    __shared__ __attribute__((aligned(16))) unsigned tile[16 * 16 * 16];        // word (n, lq, c) at ((n*16 + lq)*16 + (c ^ 4*(lq>>2)))
     __shared__ float red[16];
     const int t = threadIdx.x;
     const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 16, n0 = blockIdx.z * 16;
@@ -186,53 +198,54 @@ __global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __re
     const float q = amax > 0.f ? fmax / amax : 1.f;
     if (scale_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *scale_out = amax > 0.f ? amax / fmax : 1.f;
     float m = 0.f;
-    {
-        const int lq = t & 15, r0 = t >> 4;              // 16 lanes cover the 64 l of one (n, c) row; 16 rows per pass
-        const bool vec = (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int row = pass * 16 + r0;
-            const int n = n0 + (row >> 4), c = c0 + (row & 15);
-            const int l = l0 + 4 * lq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < N && c < C) {
-                const float* src = in + ((int64_t)n * C + c) * L + l;
-                if (vec && l + 3 < L) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (l < L) v.x = src[0];
-                    if (l + 1 < L) v.y = src[1];
-                    if (l + 2 < L) v.z = src[2];
-                    if (l + 3 < L) v.w = src[3];
-                }
+    const int lq = t & 15, cr = t >> 4;                  // this thread's pixel quad and channel of the tile
+    const int c = c0 + cr, l = l0 + 4 * lq;
+    const bool vec = (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    unsigned wn[16];                                     // word of sample n0 + pass
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+        const int n = n0 + pass;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && c < C) {
+            const float* src = in + ((int64_t)n * C + c) * L + l;
+            if (vec && l + 3 < L) {
+                v = *reinterpret_cast<const float4*>(src);
+            } else {
+                if (l < L) v.x = src[0];
+                if (l + 1 < L) v.y = src[1];
+                if (l + 2 < L) v.z = src[2];
+                if (l + 3 < L) v.w = src[3];
             }
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            const unsigned w = pack4(fminf(fmaxf(v.x * q, -fmax), fmax), fminf(fmaxf(v.y * q, -fmax), fmax),
-                                     fminf(fmaxf(v.z * q, -fmax), fmax), fminf(fmaxf(v.w * q, -fmax), fmax), fmt);
-            *reinterpret_cast<unsigned*>(&tile[row >> 4][row & 15][4 * lq]) = w;
+        }
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        wn[pass] = pack4(fminf(fmaxf(v.x * q, -fmax), fmax), fminf(fmaxf(v.y * q, -fmax), fmax),
+                         fminf(fmaxf(v.z * q, -fmax), fmax), fminf(fmaxf(v.w * q, -fmax), fmax), fmt);
+        if (a) tile[(pass * 16 + lq) * 16 + (cr ^ ((lq >> 2) << 2))] = wn[pass];
+    }
+    if (b && c < C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (l + j >= L) break;
+            const uint4 o = make_uint4(byte_of4(wn[0], wn[1], wn[2], wn[3], j), byte_of4(wn[4], wn[5], wn[6], wn[7], j),
+                                       byte_of4(wn[8], wn[9], wn[10], wn[11], j), byte_of4(wn[12], wn[13], wn[14], wn[15], j));
+            *reinterpret_cast<uint4*>(b + ((int64_t)c * L + l + j) * Np + n0) = o;
         }
     }
-    __syncthreads();
+    if (a) {
+        __syncthreads();
+        const int nr = t >> 4;                           // (sample nr, pixel quad lq) of the tile
+        if (n0 + nr < N) {
+            uint4 w4[4];                                 // w4[k] = words of channels 4k .. 4k + 3
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                        // 1024 (x, l) pairs, 4 per thread
-        const int pr = k * 256 + t;
-        const int l = pr & 63, x = pr >> 6;              // x = n for layout a, = c for layout b
-        if (l0 + l >= L) continue;
-        if (a && n0 + x < N) {
-            unsigned w[4];
+            for (int k = 0; k < 4; ++k)
+                w4[k] = *reinterpret_cast<const uint4*>(&tile[(nr * 16 + lq) * 16 + ((k ^ (lq >> 2)) << 2)]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w[j] = (unsigned)tile[x][4 * j][l] | ((unsigned)tile[x][4 * j + 1][l] << 8) | ((unsigned)tile[x][4 * j + 2][l] << 16) |
-                       ((unsigned)tile[x][4 * j + 3][l] << 24);
-            *reinterpret_cast<uint4*>(a + ((int64_t)(n0 + x) * L + l0 + l) * Cp + c0) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-        if (b && c0 + x < C) {
-            unsigned w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                w[j] = (unsigned)tile[4 * j][x][l] | ((unsigned)tile[4 * j + 1][x][l] << 8) | ((unsigned)tile[4 * j + 2][x][l] << 16) |
-                       ((unsigned)tile[4 * j + 3][x][l] << 24);
-            *reinterpret_cast<uint4*>(b + ((int64_t)(c0 + x) * L + l0 + l) * Np + n0) = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int j = 0; j < 4; ++j) {
+                if (l + j >= L) break;
+                const uint4 o = make_uint4(byte_of4(w4[0].x, w4[0].y, w4[0].z, w4[0].w, j), byte_of4(w4[1].x, w4[1].y, w4[1].z, w4[1].w, j),
+                                           byte_of4(w4[2].x, w4[2].y, w4[2].z, w4[2].w, j), byte_of4(w4[3].x, w4[3].y, w4[3].z, w4[3].w, j));
+                *reinterpret_cast<uint4*>(a + ((int64_t)(n0 + nr) * L + l + j) * Cp + c0) = o;
+            }
         }
     }
     m = rg_block_max(m, red);

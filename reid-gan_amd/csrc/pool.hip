@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gem_fwd_kernel(const float* __restrict__ 
     const float p = pp[0];
     const float* xp = x + (int64_t)plane * HW;
     float s = 0.f;
-    for (int i = lane; i < HW; i += 64) s += powf(fmaxf(xp[i], eps), p);
+    for (int i = lane; i < HW; i += 64) s += exp2f(p * log2f(fmaxf(xp[i], eps)));      // xc^p, xc >= eps > 0
     s = rg_wave_sum(s);
     if (lane == 0) y[plane] = powf(s / (float)HW, 1.f / p);
 }
@@ -178,9 +178,10 @@ __global__ __launch_bounds__(256) void gem_bwd_kernel(const float* __restrict__ 
     for (int i = lane; i < HW; i += 64) {
         const float xv = xp[i];
         const float xc = fmaxf(xv, eps);
-        const float xpw = powf(xc, p - 1.f);
+        const float l2 = log2f(xc);
+        const float xpw = exp2f((p - 1.f) * l2);                 // xc^(p-1)
         dp_[i] = xv >= eps ? coef * xpw : 0.f;
-        sl += xpw * xc * logf(xc);
+        sl += xpw * xc * (l2 * 0.6931471805599453f);
     }
     sl = rg_wave_sum(sl);
     if (lane == 0 && dp_part) {
@@ -189,10 +190,15 @@ __global__ __launch_bounds__(256) void gem_bwd_kernel(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+__global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
     __shared__ float red[16];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    const int64_t nv = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? (n >> 2) : 0;
+    for (int64_t i = threadIdx.x; i < nv; i += 1024) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += 1024) s += x[i];
     s = rg_block_sum(s, red);
     if (threadIdx.x == 0) out[0] = s;
 }
@@ -276,6 +282,6 @@ extern "C" int rg_gem_pool_bwd(const float* x, const float* p, const float* y, c
     rg::ProfScope prof(rg::FAM_POOL, stream, 0.0, 8.0 * planes * (double)HW);
     hipLaunchKernelGGL(gem_bwd_kernel, dim3(rg::cdiv(planes, 4)), dim3(256), 0, stream, x, p, y, dy, dx, part, planes, HW,
                        eps);
-    if (dp) hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, part, dp, (int64_t)planes);
+    if (dp) hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, stream, part, dp, (int64_t)planes);
     return rg::check_launch("rg_gem_pool_bwd");
 }

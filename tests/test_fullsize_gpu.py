@@ -9,7 +9,10 @@ parity tests proper run small; these cover what only shows at full size: the til
   between the overlapped (side streams) and the single-stream launch order;
 * ClusterMemory at B = 64, K = 2048, D = 2048 (config 3): touched centroids stay unit-norm, untouched rows bit-equal,
   the input gradient uses the pre-update bank;
-* kNN at Market-1501 size (12 936 x 2048, k = 15): sorted, self first, idempotent.
+* kNN at Market-1501 size (12 936 x 2048, k = 15): sorted, self first, idempotent;
+* the fp8 convolution family at BASELINE config 5's sizes (128 samples = 2 branches x 64 crops of 128x64): the three GEMMs equal the
+  fp32 MFMA convolution of the DEQUANTISED operands (fp8 x fp8 products are exact in fp32, so only the accumulation order differs),
+  both quantiser layouts hold the same bytes, power-of-two input scaling moves only the scale, two runs are bit-identical.
 """
 import math
 import os
@@ -191,3 +194,71 @@ def test_knn_properties_at_market1501_size(dev):
     rv, ri = torch.topk(ip, k, dim=1)
     assert torch.equal(ri, nbrs[rows])
     assert torch.equal(nbrs, knn_faiss(feats, k).nbrs.cpu().to(torch.long))     # deterministic, ties included
+
+
+# ---- BASELINE config 5: fp8 family at full size ---------------------------------------------------------------------------------
+def _dequant(q, shape, layout):
+    """QTensor -> fp32 NCHW on the device (torch's OCP fp8 dtypes do the byte decoding)"""
+    dt = torch.float8_e4m3fn if q.fmt == 0 else torch.float8_e5m2
+    N, C = shape[0], shape[1]
+    v = q.buf.view(dt).float() * q.scale
+    if layout == "nhwc":                                   # [N][L][Cp]
+        v = v[:, :, :C].permute(0, 2, 1)
+    else:                                                  # [C][L][Np]
+        v = v[:, :, :N].permute(2, 0, 1)
+    return v.reshape(shape).contiguous()
+
+
+@pytest.mark.parametrize("geom", [(128, 64, 128, 64, 128, 4, 2, 1),      # encoder 4x4 / 2 on the full-resolution map
+                                  (128, 128, 64, 32, 128, 3, 1, 1),      # 3x3 / 1
+                                  (128, 256, 32, 16, 256, 3, 1, 1)])     # PTM-resolution 3x3
+def test_fp8_family_properties_at_config5_size(dev, geom):
+    from rg_hip import lowp, ops
+    N, C, H, W, K, k, s, p = geom
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn(N, C, H, W, generator=g, device=dev)
+    w = torch.randn(K, C, k, k, generator=g, device=dev) / (C * k * k) ** 0.5
+    P, Q = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(N, K, P, Q, generator=g, device=dev) * 1e-3
+    st = lowp.F8States(dev, capacity=4)
+    st.policy = "jit"
+    sx, sw, sdy = st.new(lowp.E4M3), st.new(lowp.E4M3), st.new(lowp.E5M2)
+    st.finalize()
+    geomt = (N, C, H, W, K, k, k, s, s, p, p)
+
+    def run():
+        sx.prepare(x); sw.prepare(w); sdy.prepare(dy)
+        xq, xq_t = lowp.quantize_dual(x, sx)
+        wq, wq_t = lowp.quantize_dual(w, sw)
+        dyq, dyq_t = lowp.quantize_dual(dy, sdy)
+        y = lowp.conv_fwd(xq, wq, geomt)
+        dx = lowp.conv_dgrad(dyq, wq_t, geomt, (H, W))
+        dw = lowp.conv_wgrad(xq_t, dyq_t, geomt)
+        return (xq, xq_t, wq, wq_t, dyq, dyq_t), (y, dx, dw)
+
+    qs, outs = run()
+    xq, xq_t, wq, wq_t, dyq, dyq_t = qs
+    # both layouts of a tensor decode to the same values
+    xd, wd, dyd = _dequant(xq, x.shape, "nhwc"), _dequant(wq, w.shape, "nhwc"), _dequant(dyq, dy.shape, "nhwc")
+    assert torch.equal(xd, _dequant(xq_t, x.shape, "chwn"))
+    assert torch.equal(wd, _dequant(wq_t, w.shape, "chwn"))
+    assert torch.equal(dyd, _dequant(dyq_t, dy.shape, "chwn"))
+    # quantisation error within half a step of the format (e4m3: 2^-4 relative for normals), nothing saturated under jit scaling
+    assert float((xd - x).abs().max()) <= 2.0 ** -4 * float(x.abs().max())
+    # the GEMMs == fp32 MFMA convolutions of the decoded operands (independent kernels, fp32 accumulation on both sides)
+    y, dx, dw = outs
+    for got, ref, what in ((y, ops.conv2d_fwd(xd, wd, s, p), "fwd"),
+                           (dx, ops.conv2d_dgrad(dyd, wd, (H, W), s, p), "dgrad"),
+                           (dw, ops.conv2d_wgrad(xd, dyd, (K, C, k, k), s, p), "wgrad")):
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 1e-4, "%s: %.3e" % (what, err)          # the tolerance of tests/test_f8_gpu.py (MFMA-internal summation)
+    # bit-identical between runs
+    _, outs2 = run()
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    # a power-of-two rescaling of the input changes the scale only: same bytes, output exactly 4 x
+    x4 = x * 4.0
+    sx.prepare(x4)
+    x4q, _ = lowp.quantize_dual(x4, sx, True, False)
+    assert torch.equal(x4q.buf, xq.buf) and float(x4q.scale) == 4.0 * float(xq.scale)
+    assert torch.equal(lowp.conv_fwd(x4q, wq, geomt), y * 4.0)
