@@ -188,15 +188,32 @@ __device__ __forceinline__ unsigned byte_of4(unsigned w0, unsigned w1, unsigned 
 __global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __restrict__ in, unsigned char* __restrict__ a,
                                                                unsigned char* __restrict__ b, float* __restrict__ state,
                                                                float* __restrict__ scale_out, int fmt, int N, int C, int L,
-                                                               int Cp, int Np) {
+                                                               int Cp, int Np, int xcd_groups) {
     __shared__ __attribute__((aligned(16))) unsigned tile[16 * 16 * 16];        // word (n, lq, c) at ((n*16 + lq)*16 + (c ^ 4*(lq>>2)))
     __shared__ float red[16];
     const int t = threadIdx.x;
-    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 16, n0 = blockIdx.z * 16;
+    // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD and all (c, n) tiles of one
+    // pixel tile are consecutive workgroups of ONE XCD — the 16-byte pieces they write into the same 64 / 128-byte rows of `a`
+    // (c tiles) and `b` (n tiles) meet in that XCD's L2 and leave it as full lines
+    // (maps with fewer than 16 pixel tiles keep the plain order — pixel tile fastest — which spreads them over all XCDs)
+    const int ct = Cp >> 4, nt = Np >> 4;
+    const int per = ct * nt;
+    int ltile, r;
+    if (xcd_groups) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        ltile = (k / per) * 8 + xcd;
+        r = k - (k / per) * per;
+    } else {
+        const int lt = (L + 63) >> 6;
+        r = blockIdx.x / lt;
+        ltile = blockIdx.x - r * lt;
+    }
+    const int l0 = ltile * 64, c0 = (r % ct) * 16, n0 = (r / ct) * 16;
+    if (l0 >= L) return;                                 // whole workgroup: the pixel-tile count is padded to a multiple of 8
     const float amax = state[0];
     const float fmax = f8_max(fmt);
     const float q = amax > 0.f ? fmax / amax : 1.f;
-    if (scale_out && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *scale_out = amax > 0.f ? amax / fmax : 1.f;
+    if (scale_out && t == 0 && blockIdx.x == 0) *scale_out = amax > 0.f ? amax / fmax : 1.f;
     float m = 0.f;
     const int lq = t & 15, cr = t >> 4;                  // this thread's pixel quad and channel of the tile
     const int c = c0 + cr, l = l0 + 4 * lq;
@@ -614,10 +631,14 @@ extern "C" int rg_f8_quantize_dual(const float* in, void* a, void* b, float* sta
                                    hipStream_t stream) {
     RG_REQUIRE(in && (a || b) && state && (fmt == 0 || fmt == 1) && N > 0 && C > 0 && L > 0, "rg_f8_quantize_dual: bad arguments");
     const int Cp = pad16(C), Np = pad16(N);
-    RG_REQUIRE(Cp / 16 <= 65535 && Np / 16 <= 65535, "rg_f8_quantize_dual: dimension exceeds the grid limit");
+    const int lt = rg::cdiv(L, 64);
+    const int xcd_groups = lt >= 16 ? 1 : 0;
+    const int64_t wgs = (int64_t)(xcd_groups ? rg::cdiv(lt, 8) * 8 : lt) * (Cp / 16) * (Np / 16);
+    RG_REQUIRE(wgs < (1ll << 31), "rg_f8_quantize_dual: tensor exceeds the grid limit");
     rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, (double)L * (4.0 * N * C + (a ? (double)N * Cp : 0.0) + (b ? (double)C * Np : 0.0)));
-    hipLaunchKernelGGL(f8_quantize_dual_kernel, dim3(rg::cdiv(L, 64), Cp / 16, Np / 16), dim3(256), 0, stream, in,
-                       static_cast<unsigned char*>(a), static_cast<unsigned char*>(b), state, scale_out, fmt, N, C, L, Cp, Np);
+    hipLaunchKernelGGL(f8_quantize_dual_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, in,
+                       static_cast<unsigned char*>(a), static_cast<unsigned char*>(b), state, scale_out, fmt, N, C, L, Cp, Np,
+                       xcd_groups);
     return rg::check_launch("rg_f8_quantize_dual");
 }
 
