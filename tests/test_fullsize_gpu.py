@@ -13,6 +13,8 @@ parity tests proper run small; these cover what only shows at full size: the til
 * the fp8 convolution family at BASELINE config 5's sizes (128 samples = 2 branches x 64 crops of 128x64): the three GEMMs equal the
   fp32 MFMA convolution of the DEQUANTISED operands (fp8 x fp8 products are exact in fp32, so only the accumulation order differs),
   both quantiser layouts hold the same bytes, power-of-two input scaling moves only the scale, two runs are bit-identical.
+* BASELINE config 1 as stated (the reference's own CPU-runnable case): `extract_cnn_feature` of `create('resnet50',
+  cut_at_pooling=True)` in eval mode on 64 crops of 256x128 -> [64, 2048], compared DIRECTLY with the oracle's CPU forward (1e-3).
 """
 import math
 import os
@@ -262,3 +264,32 @@ def test_fp8_family_properties_at_config5_size(dev, geom):
     x4q, _ = lowp.quantize_dual(x4, sx, True, False)
     assert torch.equal(x4q.buf, xq.buf) and float(x4q.scale) == 4.0 * float(xq.scale)
     assert torch.equal(lowp.conv_fwd(x4q, wq, geomt), y * 4.0)
+
+
+def test_config1_eval_features_64_crops_against_the_oracle(dev):
+    """BASELINE config 1 at its full size: 64 x 5.34 GFLOP on the host for the oracle (seconds on the GPU box's cores)."""
+    from oracle import ref_torch as O
+    import reid.models as RM
+    from reid.feature_extraction import extract_cnn_feature
+    torch.manual_seed(11)
+    o = O.OReidResNet(50, cut_at_pooling=True)
+    g = torch.Generator().manual_seed(12)
+    for m in o.modules():                                  # non-trivial frozen statistics, as a trained checkpoint has
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+    r = RM.create('resnet50', cut_at_pooling=True, pretrained=False)
+    r.load_state_dict(o.state_dict())
+    r.to(dev)
+    x = O.synth_images(64, seed=4)
+    o.eval()
+    with torch.no_grad():
+        ref = o(x)
+    got = extract_cnn_feature(r, x)
+    assert got.shape == (64, 2048) and not r.training
+    err = (got.double() - ref.double()).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-3, err
+    # each crop's feature is independent of its batch neighbours (frozen statistics): two half batches give the same rows
+    half = torch.cat([extract_cnn_feature(r, x[:32]), extract_cnn_feature(r, x[32:])])
+    assert (half - got).abs().max().item() <= 1e-5 * got.abs().max().item()
