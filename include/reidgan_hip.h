@@ -106,6 +106,17 @@ int rg_bn_apply_fwd(const float* x, const float* mean, const float* stat, const 
 int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const float* mean, const float* stat,
                      float* sum_dy, float* sum_dy_xhat, int N, int C, int HW, int stat_is_var, float eps, int act,
                      float slope, void* workspace, size_t workspace_bytes, rg_stream_t stream);
+/* Train-mode torch.nn.BatchNorm2d / 1d (FD/fdgan/networks.py:28, CC/clustercontrast/models/resnet.py trunk) in one launch per
+ * direction for small per-channel extents (rg_bn_train_fused_ok: N*HW <= 16384 and C >= 128): forward computes the batch statistics,
+ * updates the running statistics, writes mean / invstd [C] and y = act(gamma*xhat + beta + residual); backward writes the channel sums
+ * of g = dy*act'(y) and g*xhat (dbeta / dgamma) and dx / dres (either may be NULL). */
+int rg_bn_train_fused_ok(int N, int C, int HW);
+int rg_bn_train_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                          float* invstd, float* running_mean, float* running_var, int N, int C, int HW, float eps, float momentum,
+                          int act, float slope, rg_stream_t stream);
+int rg_bn_train_bwd_fused(const float* x, const float* dy, const float* y_act, const float* mean, const float* invstd,
+                          const float* gamma, float* dx, float* dres, float* sum_dy, float* sum_dy_xhat, int N, int C, int HW,
+                          int act, float slope, rg_stream_t stream);
 /* torch.nn.InstanceNorm2d (affine or not; FD/fdgan/networks.py:30, CC/dual_gan/models/base_function.py:38-49) in one launch per
  * direction: forward writes y = act(gamma[c] * xhat + beta[c] + residual) and the per-instance mean / invstd [N*C]; backward
  * writes dx, dres (either may be NULL), the per-instance sums of g = dy*act'(y) and g*xhat [N*C] and, when sum_dx is given, the

@@ -794,6 +794,164 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
     }
 }
 
+// ---- train-mode BatchNorm in one launch per direction, small per-channel extents ----------------------------------------------
+// One workgroup per channel: its N rows of HW floats (stride C*HW) are <= 64 KB, so passes two and three hit L1 / L2.  Used when
+// N*HW <= 16384 and the channel count alone fills the chip (layer3 / layer4 of the ResNets, the inner generator layers); the
+// slice-parallel kernels above stay for the large maps.  Statistics as bn_stats (biased variance for the normalisation, unbiased
+// for running_var), two-pass.
+__device__ __forceinline__ float bn_block_sum(float v, float* red) {
+    v = rg_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_train_fwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ res,
+                                                                 float* __restrict__ y, float* __restrict__ mean_out,
+                                                                 float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var, int N, int C, int HW, float eps,
+                                                                 float momentum, int act, float slope) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const bool vec = (HW & 3) == 0;
+    const int rl = vec ? HW >> 2 : HW;                   // units (float4 or float) per row
+    const int total = N * rl;
+    const int64_t cs = (int64_t)C * HW;
+    const float cnt = (float)N * (float)HW;
+    float s = 0.f;
+    for (int i = t; i < total; i += 256) {
+        const int n = i / rl, v = i - n * rl;
+        const float* p = x + (int64_t)n * cs + (int64_t)c * HW;
+        if (vec) {
+            const float4 a = reinterpret_cast<const float4*>(p)[v];
+            s += (a.x + a.y) + (a.z + a.w);
+        } else {
+            s += p[v];
+        }
+    }
+    const float mu = bn_block_sum(s, red) / cnt;
+    float q = 0.f;
+    for (int i = t; i < total; i += 256) {
+        const int n = i / rl, v = i - n * rl;
+        const float* p = x + (int64_t)n * cs + (int64_t)c * HW;
+        if (vec) {
+            const float4 a = reinterpret_cast<const float4*>(p)[v];
+            const float d0 = a.x - mu, d1 = a.y - mu, d2 = a.z - mu, d3 = a.w - mu;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        } else {
+            const float d = p[v] - mu;
+            q += d * d;
+        }
+    }
+    const float m2 = bn_block_sum(q, red);
+    const float var = m2 / cnt;
+    const float is = rsqrtf(var + eps);
+    if (t == 0) {
+        mean_out[c] = mu;
+        invstd_out[c] = is;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (cnt > 1.f ? m2 / (cnt - 1.f) : var);
+    }
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float sh = (beta ? beta[c] : 0.f) - mu * gs;
+    for (int i = t; i < total; i += 256) {
+        const int n = i / rl, v = i - n * rl;
+        const int64_t off = (int64_t)n * cs + (int64_t)c * HW;
+        if (vec) {
+            const float4 a = reinterpret_cast<const float4*>(x + off)[v];
+            float4 o;
+            o.x = a.x * gs + sh; o.y = a.y * gs + sh; o.z = a.z * gs + sh; o.w = a.w * gs + sh;
+            if (res) {
+                const float4 r = reinterpret_cast<const float4*>(res + off)[v];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            o.x = rg_apply_act(o.x, act, slope); o.y = rg_apply_act(o.y, act, slope);
+            o.z = rg_apply_act(o.z, act, slope); o.w = rg_apply_act(o.w, act, slope);
+            reinterpret_cast<float4*>(y + off)[v] = o;
+        } else {
+            float o = x[off + v] * gs + sh;
+            if (res) o += res[off + v];
+            y[off + v] = rg_apply_act(o, act, slope);
+        }
+    }
+}
+
+// g = dy * act'(y); sum_dy[c] = sum g, sum_dy_xhat[c] = sum g * xhat; dx = gamma * invstd * (g - mean(g) - xhat * mean(g xhat)); dres = g
+__global__ __launch_bounds__(256) void bn_train_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ yact, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 float* __restrict__ dx, float* __restrict__ dres,
+                                                                 float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat, int N,
+                                                                 int C, int HW, int act, float slope) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const bool vec = (HW & 3) == 0;
+    const int rl = vec ? HW >> 2 : HW;
+    const int total = N * rl;
+    const int64_t cs = (int64_t)C * HW;
+    const float cnt = (float)N * (float)HW;
+    const float mu = mean[c], is = invstd[c];
+    const bool has_act = act != RG_ACT_NONE;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = t; i < total; i += 256) {
+        const int n = i / rl, v = i - n * rl;
+        const int64_t off = (int64_t)n * cs + (int64_t)c * HW;
+        if (vec) {
+            float4 g = reinterpret_cast<const float4*>(dy + off)[v];
+            if (has_act) {
+                const float4 yv = reinterpret_cast<const float4*>(yact + off)[v];
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            const float4 a = reinterpret_cast<const float4*>(x + off)[v];
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * (a.x - mu) + g.y * (a.y - mu)) + (g.z * (a.z - mu) + g.w * (a.w - mu));
+        } else {
+            float g = dy[off + v];
+            if (has_act) g *= act_grad_from_out(yact[off + v], act, slope);
+            s1 += g;
+            s2 += g * (x[off + v] - mu);
+        }
+    }
+    s1 = bn_block_sum(s1, red);
+    s2 = bn_block_sum(s2, red) * is;
+    if (t == 0) {
+        sum_dy[c] = s1;
+        sum_dy_xhat[c] = s2;
+    }
+    if (!dx && !dres) return;
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float a0 = s1 / cnt, b0 = s2 / cnt * is;
+    for (int i = t; i < total; i += 256) {
+        const int n = i / rl, v = i - n * rl;
+        const int64_t off = (int64_t)n * cs + (int64_t)c * HW;
+        if (vec) {
+            float4 g = reinterpret_cast<const float4*>(dy + off)[v];
+            if (has_act) {
+                const float4 yv = reinterpret_cast<const float4*>(yact + off)[v];
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (dres) reinterpret_cast<float4*>(dres + off)[v] = g;
+            if (dx) {
+                const float4 a = reinterpret_cast<const float4*>(x + off)[v];
+                float4 o;
+                o.x = gs * (g.x - a0 - (a.x - mu) * b0); o.y = gs * (g.y - a0 - (a.y - mu) * b0);
+                o.z = gs * (g.z - a0 - (a.z - mu) * b0); o.w = gs * (g.w - a0 - (a.w - mu) * b0);
+                reinterpret_cast<float4*>(dx + off)[v] = o;
+            }
+        } else {
+            float g = dy[off + v];
+            if (has_act) g *= act_grad_from_out(yact[off + v], act, slope);
+            if (dres) dres[off + v] = g;
+            if (dx) dx[off + v] = gs * (g - a0 - (x[off + v] - mu) * b0);
+        }
+    }
+}
+
 // out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c] (fixed summation order): the affine gradients of an InstanceNorm from the per-(n,c) sums
 // its backward reduction already produced.  Either pair may be NULL.
 __global__ __launch_bounds__(256) void rows_sum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -830,6 +988,35 @@ extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, fl
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * ((a ? 1 : 0) + (b ? 1 : 0)) * (double)(N + 1) * C);
     hipLaunchKernelGGL(rows_sum_pair_kernel, dim3(rg::cdiv(C, 16)), dim3(256), 0, stream, a, b, out_a, out_b, N, C);
     return rg::check_launch("rg_rows_sum_pair");
+}
+
+// Train-mode BatchNorm, one launch per direction (see the kernels): rg_bn_train_fused_ok says whether the geometry qualifies;
+// otherwise use rg_bn_stats + rg_bn_apply_fwd / rg_bn_bwd_reduce + rg_bn_bwd_apply.
+extern "C" int rg_bn_train_fused_ok(int N, int C, int HW) {
+    return (int64_t)N * HW <= 16384 && C >= 128 ? 1 : 0;
+}
+
+extern "C" int rg_bn_train_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                     float* mean, float* invstd, float* running_mean, float* running_var, int N, int C, int HW,
+                                     float eps, float momentum, int act, float slope, hipStream_t stream) {
+    RG_REQUIRE(x && y && mean && invstd && N > 0 && C > 0 && HW > 0, "rg_bn_train_fwd_fused: bad arguments");
+    RG_REQUIRE((int64_t)N * HW < (1ll << 30), "rg_bn_train_fwd_fused: N*HW too large");
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * N * (double)C * HW);
+    hipLaunchKernelGGL(bn_train_fwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd,
+                       running_mean, running_var, N, C, HW, eps, momentum, act, slope);
+    return rg::check_launch("rg_bn_train_fwd_fused");
+}
+
+extern "C" int rg_bn_train_bwd_fused(const float* x, const float* dy, const float* y_act, const float* mean, const float* invstd,
+                                     const float* gamma, float* dx, float* dres, float* sum_dy, float* sum_dy_xhat, int N, int C,
+                                     int HW, int act, float slope, hipStream_t stream) {
+    RG_REQUIRE(x && dy && mean && invstd && sum_dy && sum_dy_xhat && N > 0 && C > 0 && HW > 0, "rg_bn_train_bwd_fused: bad arguments");
+    RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_bn_train_bwd_fused: fused activation needs the forward output");
+    RG_REQUIRE((int64_t)N * HW < (1ll << 30), "rg_bn_train_bwd_fused: N*HW too large");
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, ((act ? 12.0 : 8.0) + (dx ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)) * N * (double)C * HW);
+    hipLaunchKernelGGL(bn_train_bwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres, sum_dy,
+                       sum_dy_xhat, N, C, HW, act, slope);
+    return rg::check_launch("rg_bn_train_bwd_fused");
 }
 
 // InstanceNorm2d forward: y = act(gamma[c] * (x - mean[n,c]) * invstd[n,c] + beta[c] + residual); mean / invstd [N*C] are kept for

@@ -141,7 +141,8 @@ class Conv2d(RGModule, _KrscCache):
             want_w = tape.wants(self.weight)
             dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
             if want_w:
-                tape.add_grad(self.weight, lowp.conv_wgrad(xq_t, dyq_t, geom, out=tape.grad_out(self.weight)))
+                gout = tape.grad_out(self.weight)
+                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(xq_t, dyq_t, geom, out=gout), xq_t, dyq_t, gout))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:
@@ -240,7 +241,8 @@ class ConvTranspose2d(RGModule, _KrscCache):
             dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
             if want_w:
                 # filter gradient with the roles swapped: the "input" is dy (e5m2), the "output gradient" is x (e4m3)
-                tape.add_grad(self.weight, lowp.conv_wgrad(dyq_t, xq_t, geom, out=tape.grad_out(self.weight)))
+                gout = tape.grad_out(self.weight)
+                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(dyq_t, xq_t, geom, out=gout), xq_t, dyq_t, gout))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:
@@ -342,12 +344,18 @@ class _BatchNorm(RGModule):
         if batch_stats:
             rm = self.running_mean if self.track_running_stats else None
             rv = self.running_var if self.track_running_stats else None
-            mean, stat = ops.bn_stats(x, rm, rv, self.eps, self.momentum)
-            is_var = False
             if self.track_running_stats:
                 # bookkeeping counter (int64 buffer): counted on the host, written to the buffer when someone looks
                 # (attribute access, state_dict) instead of one tiny device launch per layer and step
                 self.__dict__["_nbt_pending"] = self.__dict__.get("_nbt_pending", 0) + 1
+            if ops.bn_train_fused_ok(x):
+                # small per-channel extent: statistics, running-statistics update and the normalisation in ONE launch
+                y, mean, stat = ops.bn_train_fwd_fused(x, self.weight, self.bias, residual, rm, rv, self.eps, self.momentum, act,
+                                                       slope)
+                tape.push((x, y if act != ACT_NONE else None, mean, stat, False, True, act, slope, residual is not None))
+                return y
+            mean, stat = ops.bn_stats(x, rm, rv, self.eps, self.momentum)
+            is_var = False
         else:
             mean, stat, is_var = self.running_mean, self.running_var, True
         y = ops.bn_apply_fwd(x, mean, stat, self.weight, self.bias, residual, is_var, self.eps, act, slope)
@@ -374,6 +382,17 @@ class _BatchNorm(RGModule):
                 tape.add_grad(self.bias, s1)
             return (dx, dres) if has_res else dx
         s1 = s2 = None
+        if train and not is_var and ops.bn_train_fused_ok(x):
+            o1 = tape.grad_out(self.bias) if tape.wants(self.bias) else None
+            o2 = tape.grad_out(self.weight) if tape.wants(self.weight) else None
+            dx, dres, s1, s2 = ops.bn_train_bwd_fused(x, dy, y, mean, stat, self.weight, act, slope,
+                                                      need_dx=need_dx or not has_res, need_dres=has_res,
+                                                      out_sum_dy=o1, out_sum_dy_xhat=o2)
+            if tape.wants(self.weight):
+                tape.add_grad(self.weight, s2)
+            if tape.wants(self.bias):
+                tape.add_grad(self.bias, s1)
+            return (dx, dres) if has_res else dx
         if need_affine or (train and need_dx):
             o1 = tape.grad_out(self.bias) if tape.wants(self.bias) else None
             o2 = tape.grad_out(self.weight) if tape.wants(self.weight) else None
@@ -837,9 +856,10 @@ class SNConv2d(RGModule):
             want_w = tape.wants(self.weight_orig)
             dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
             if want_w:
-                dw_sn = lowp.conv_wgrad(x, dyq_t, geom)
-                tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,
-                                                                      out=tape.grad_out(self.weight_orig)))
+                gout = tape.grad_out(self.weight_orig)
+                tape.add_grad(self.weight_orig, ops.side_call(
+                    lambda: ops.spectral_norm_bwd(lowp.conv_wgrad(x, dyq_t, geom), w_sn, u, v, sigma, out=gout),
+                    x, dyq_t, w_sn, u, v, sigma, gout))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:

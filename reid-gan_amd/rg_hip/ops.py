@@ -216,6 +216,24 @@ def side_join():
         sess.used = False
 
 
+def side_call(fn, *operands):
+    """run `fn()` — a leaf of the backward program (weight-gradient work) — on the session's side stream, ordered behind
+    everything the main stream has launched so far; `operands` (and fn's result) stay referenced until the join.  Inline when
+    no session is open or the side stream is switched off."""
+    if _SIDE["on"]:
+        main, sess = _side_session(create=False)
+        if sess is not None and sess.depth > 0:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            sess.stream.wait_event(ev)
+            with torch.cuda.stream(sess.stream):
+                out = fn()
+            sess.refs.append((operands, out, fn))
+            sess.used = True
+            return out
+    return fn()
+
+
 def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
     """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
     behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
@@ -321,6 +339,44 @@ def bn_bwd_reduce(x, dy, y_act, mean, stat, stat_is_var=False, eps=1e-5, act=ACT
     lib.rg_bn_bwd_reduce(_p(x), _p(dy), _p(y_act), _p(mean), _p(stat), _p(sum_dy), _p(sum_dy_xhat), N, C, HW,
                          int(stat_is_var), eps, act, slope, _p(ws), ws.numel(), _stream())
     return sum_dy, sum_dy_xhat
+
+
+_BN_FUSED = os.environ.get("RG_BN_FUSED", "1") != "0"
+
+
+def bn_train_fused_ok(x):
+    """does this activation qualify for the one-launch train-mode BatchNorm kernels (small per-channel extent, many channels)?"""
+    if not _BN_FUSED:
+        return False
+    N, C, HW = _nchw(x)
+    return bool(_ws_query("rg_bn_train_fused_ok", N, C, HW))
+
+
+def bn_train_fwd_fused(x, gamma, beta, residual, running_mean, running_var, eps, momentum, act=ACT_NONE, slope=0.0):
+    """batch statistics + running-statistics update + normalise + affine + residual + activation -> (y, mean[C], invstd[C])"""
+    x, residual = _chk(x, "x"), _chk(residual, "residual")
+    _same_size("bn_train_fwd_fused", x, residual=residual)
+    N, C, HW = _nchw(x)
+    y = torch.empty_like(x)
+    stats = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    lib.rg_bn_train_fwd_fused(_p(x), _p(gamma), _p(beta), _p(residual), _p(y), _p(stats[0]), _p(stats[1]), _p(running_mean),
+                              _p(running_var), N, C, HW, eps, momentum, act, slope, _stream())
+    return y, stats[0], stats[1]
+
+
+def bn_train_bwd_fused(x, dy, y_act, mean, invstd, gamma, act=ACT_NONE, slope=0.0, need_dx=True, need_dres=False,
+                       out_sum_dy=None, out_sum_dy_xhat=None):
+    """-> (dx, dres, sum_g[C], sum_g_xhat[C]) in one launch"""
+    x, dy, y_act = _chk(x, "x"), _chk(dy, "dy"), _chk(y_act, "y")
+    _same_size("bn_train_bwd_fused", dy, x=x, y=y_act)
+    N, C, HW = _nchw(x)
+    dx = torch.empty_like(dy) if need_dx else None
+    dres = torch.empty_like(dy) if need_dres else None
+    s1 = out_sum_dy if out_sum_dy is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    s2 = out_sum_dy_xhat if out_sum_dy_xhat is not None else torch.empty(C, dtype=torch.float32, device=x.device)
+    lib.rg_bn_train_bwd_fused(_p(x), _p(dy), _p(y_act), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dres), _p(s1), _p(s2), N, C, HW,
+                              act, slope, _stream())
+    return dx, dres, s1, s2
 
 
 def instnorm_fwd(x, gamma=None, beta=None, residual=None, eps=1e-5, act=ACT_NONE, slope=0.0):
