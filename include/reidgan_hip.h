@@ -110,7 +110,7 @@ int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_act, const 
  * direction for small per-channel extents (rg_bn_train_fused_ok: N*HW <= 16384 and C >= 128): forward computes the batch statistics,
  * updates the running statistics, writes mean / invstd [C] and y = act(gamma*xhat + beta + residual); backward writes the channel sums
  * of g = dy*act'(y) and g*xhat (dbeta / dgamma) and dx / dres (either may be NULL). */
-int rg_bn_train_fused_ok(int N, int C, int HW);
+size_t rg_bn_train_fused_ok(int N, int C, int HW);
 int rg_bn_train_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
                           float* invstd, float* running_mean, float* running_var, int N, int C, int HW, float eps, float momentum,
                           int act, float slope, rg_stream_t stream);

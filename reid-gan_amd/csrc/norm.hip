@@ -992,7 +992,7 @@ extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, fl
 
 // Train-mode BatchNorm, one launch per direction (see the kernels): rg_bn_train_fused_ok says whether the geometry qualifies;
 // otherwise use rg_bn_stats + rg_bn_apply_fwd / rg_bn_bwd_reduce + rg_bn_bwd_apply.
-extern "C" int rg_bn_train_fused_ok(int N, int C, int HW) {
+extern "C" size_t rg_bn_train_fused_ok(int N, int C, int HW) {
     return (int64_t)N * HW <= 16384 && C >= 128 ? 1 : 0;
 }
 

@@ -31,6 +31,17 @@ def test_queries_and_error_convention_without_gpu():
     assert lib.rg_family_count() == len(L.FAMILIES)
     assert lib.rg_loss_workspace() >= 1024
     assert lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32) > 0
+    # every host-only query of the header answers on a machine without a GPU; queries return VALUES (size_t), never a status —
+    # an `int` prototype would be read as an error code by the binding
+    protos = L.parse_header()
+    queries = {"rg_conv2d_fwd_workspace": (32, 64, 64, 3, 3, 64, 32), "rg_conv2d_dgrad_workspace": (32, 64, 64, 32, 64, 3, 3, 1, 1),
+               "rg_conv2d_wgrad_workspace": (32, 64, 64, 3, 3, 64, 32), "rg_bn_workspace": (32, 64, 2048),
+               "rg_bn_train_fused_ok": (64, 1024, 128), "rg_conv2d_f8_wgrad_workspace": (32, 64, 64, 3, 3, 64, 32),
+               "rg_spectral_norm_bwd_workspace": (256, 2304), "rg_loss_workspace": ()}
+    assert sorted(queries) == sorted(n for n, (ret, _) in protos.items() if ret == "size_t")
+    for name, a in queries.items():
+        assert getattr(lib, name)(*a) >= 0, name
+    assert lib.rg_bn_train_fused_ok(64, 1024, 128) == 1 and lib.rg_bn_train_fused_ok(64, 64, 2048) == 0
     with pytest.raises(RuntimeError) as e:
         lib.rg_fill(None, 4, 1.0, None)
     assert "rg_fill" in str(e.value)
