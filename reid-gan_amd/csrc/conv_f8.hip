@@ -312,12 +312,18 @@ __device__ __forceinline__ floatx16 mfma8(int8v a, int8v b, floatx16 c) {
 __device__ __forceinline__ unsigned lds_off(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row >> 2)) & 3) * 16u; }
 
 // MODE 0 forward, 1 data gradient (blockIdx.z = class), 2 weight gradient (blockIdx.z = split)
-template <int MODE, int BM, int FA, int FB>
+// NB = 2: operands staged through registers (global -> VGPR -> ds_write), two LDS buffers, prefetch distance one k-tile.
+// NB > 2: LDS-DMA ring (buffer_load ... lds, 16 bytes per lane): no staging registers, NB - 1 k-tiles in flight per workgroup.  A
+//         k-tile is only 64 reduction bytes = one MFMA step per 32x32 block (~100 ns of matrix work per workgroup), so the loop is
+//         bound by load LATENCY, not by issue: the ring plus 2-3 resident workgroups keeps ~10 tiles per CU in flight.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int MODE, int BM, int FA, int FB, int NB>
 __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int AR = BM / 64;              // A rows staged per thread (64 rows per pass)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][(BM + BN) * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NB][(BM + BN) * ROWB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -387,46 +393,67 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto load_tile = [&](int kt) {
-        const int q = kt * 4 + ch;                 // chunk index along the reduction
+    // byte offsets (or OOB) of the 16-byte chunks this thread stages for k-tile kt; `chx` = its chunk of the 64-byte row
+    auto tile_offsets = [&](int kt, int chx, unsigned (&oa)[AR], unsigned (&ob)[2]) {
+        const int q = kt * 4 + chx;                // chunk index along the reduction
         const bool qok = q < Kc;
         const int t = fdiv(q, p.d_cq);             // fwd: filter tap; dgrad: tap of the class; wgrad: output pixel
         const int cc = q - t * p.Cq;
         if (MODE == 0) {
             const int r = fdiv(t, p.d_kw), s = t - r * p.KW;
 #pragma unroll
-            for (int i = 0; i < AR; ++i)
-                sa_[i] = bload16(ra, (aok[i] && qok) ? (unsigned)(arow[i] * Kc + q) * 16u : OOB);
+            for (int i = 0; i < AR; ++i) oa[i] = (aok[i] && qok) ? (unsigned)(arow[i] * Kc + q) * 16u : OOB;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int h = b_y[i] + r, w = b_x[i] + s;
                 const bool ok = bok[i] && qok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-                sb_[i] = bload16(rb, ok ? (unsigned)(((b_img[i] * p.H + h) * p.W + w) * p.Cq + cc) * 16u : OOB);
+                ob[i] = ok ? (unsigned)(((b_img[i] * p.H + h) * p.W + w) * p.Cq + cc) * 16u : OOB;
             }
         } else if (MODE == 1) {
             const int j = fdiv(t, cl.d_nrw), jj = t - j * cl.nrw;
             const int rs = (cl.r0 + p.SH * j) * p.KW + cl.s0 + p.SW * jj;
 #pragma unroll
-            for (int i = 0; i < AR; ++i)
-                sa_[i] = bload16(ra, (aok[i] && qok) ? (unsigned)((arow[i] * RS + rs) * p.Cq + cc) * 16u : OOB);
+            for (int i = 0; i < AR; ++i) oa[i] = (aok[i] && qok) ? (unsigned)((arow[i] * RS + rs) * p.Cq + cc) * 16u : OOB;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pp = b_y[i] - j, qq = b_x[i] - jj;
                 const bool ok = bok[i] && qok && (unsigned)pp < (unsigned)p.P && (unsigned)qq < (unsigned)p.Q;
-                sb_[i] = bload16(rb, ok ? (unsigned)(((b_img[i] * p.P + pp) * p.Q + qq) * p.Cq + cc) * 16u : OOB);
+                ob[i] = ok ? (unsigned)(((b_img[i] * p.P + pp) * p.Q + qq) * p.Cq + cc) * 16u : OOB;
             }
         } else {
             const int pp = fdiv(t, p.d_q), qq = t - pp * p.Q;
 #pragma unroll
-            for (int i = 0; i < AR; ++i)
-                sa_[i] = bload16(ra, (aok[i] && qok) ? (unsigned)((arow[i] * PQ + t) * p.Cq + cc) * 16u : OOB);
+            for (int i = 0; i < AR; ++i) oa[i] = (aok[i] && qok) ? (unsigned)((arow[i] * PQ + t) * p.Cq + cc) * 16u : OOB;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int h = pp * p.SH + b_y[i], w = qq * p.SW + b_x[i];
                 const bool ok = bok[i] && qok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-                sb_[i] = bload16(rb, ok ? (unsigned)((b_img[i] * HW + h * p.W + w) * p.Cq + cc) * 16u : OOB);
+                ob[i] = ok ? (unsigned)((b_img[i] * HW + h * p.W + w) * p.Cq + cc) * 16u : OOB;
             }
         }
+    };
+    auto load_tile = [&](int kt) {
+        unsigned oa[AR], ob[2];
+        tile_offsets(kt, ch, oa, ob);
+#pragma unroll
+        for (int i = 0; i < AR; ++i) sa_[i] = bload16(ra, oa[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sb_[i] = bload16(rb, ob[i]);
+    };
+    // LDS-DMA: lane l of wave w lands at (w*64 + l) * 16 bytes of the 4 KiB pass = row w*16 + l/4, physical chunk l%4, so the lane
+    // fetches the LOGICAL chunk whose swizzled position that is (the XOR is an involution); out-of-range chunks arrive as zeros
+    const int che = ch ^ ((srow >> 2) & 3);
+    const unsigned lds_lane0 = (unsigned)__builtin_amdgcn_readfirstlane(wid) * 1024u;
+    auto dma_tile = [&](int kt, int buf) {
+        unsigned oa[AR], ob[2];
+        tile_offsets(kt, che, oa, ob);
+        unsigned char* base = lds[buf] + lds_lane0;
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + i * 4096), 16, (int)oa[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + BM * ROWB + i * 4096), 16, (int)ob[i], 0, 0, 0);
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -441,20 +468,9 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
         kt_begin = (int)blockIdx.z * p.ktiles_per_split;
         kt_end = min(kt_begin + p.ktiles_per_split, nk);
     }
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
     const int l32 = lane & 31, lh = lane >> 5;
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool has_next = kt + 1 < kt_end;
-        if (has_next) load_tile(kt + 1);
-        const unsigned char* As = lds[cur];
-        const unsigned char* Bs = lds[cur] + BM * ROWB;
-        {
-            int8v a[TM], b[TN];
+    auto compute_tile = [&](const unsigned char* As, const unsigned char* Bs) {
+        int8v a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm * WTM + i * 32 + l32;
@@ -473,10 +489,44 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma8<FA, FB>(a[i], b[j], acc[i][j]);
+    };
+    if (NB == 2) {
+        if (kt_begin < kt_end) {
+            load_tile(kt_begin);
+            store_tile(0);
         }
-        if (has_next) store_tile(cur ^ 1);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool has_next = kt + 1 < kt_end;
+            if (has_next) load_tile(kt + 1);
+            compute_tile(lds[cur], lds[cur] + BM * ROWB);
+            if (has_next) store_tile(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        constexpr int LPT = AR + 2;                // DMA instructions per thread and k-tile
+        const int nkt = kt_end - kt_begin;
+#pragma unroll
+        for (int sidx = 0; sidx < NB - 1; ++sidx)
+            if (sidx < nkt) dma_tile(kt_begin + sidx, sidx);
+        int buf = 0;
+        for (int it = 0; it < nkt; ++it) {
+            // tile `it` has landed once at most the younger tiles' DMAs (issued after it) are outstanding
+            const int younger = min(NB - 2, nkt - 1 - it);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave's part of tile `it` is in LDS; every wave is done reading tile it-1
+            if (it + NB - 1 < nkt) {
+                int nbuf = buf + NB - 1;
+                if (nbuf >= NB) nbuf -= NB;
+                dma_tile(kt_begin + it + NB - 1, nbuf);          // into the buffer tile it-1 used
+            }
+            compute_tile(lds[buf], lds[buf] + BM * ROWB);
+            if (++buf == NB) buf = 0;
+        }
     }
 
     // ---- epilogue ----
@@ -498,9 +548,23 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
         return;
     }
     const float scale = p.sa[0] * p.sb[0];
-    const rsrc_t rsh = make_rsrc(p.shift ? p.shift : p.sa, p.shift ? (unsigned)p.M * 4u : 0u);
-    const rsrc_t rr = make_rsrc(p.res ? (const void*)p.res : (const void*)p.out, p.res ? p.out_bytes : 0u);
+    const bool has_shift = p.shift != nullptr, has_res = p.res != nullptr;       // uniform
+    const rsrc_t rsh = make_rsrc(has_shift ? p.shift : p.sa, has_shift ? (unsigned)p.M * 4u : 0u);
+    const rsrc_t rr = make_rsrc(has_res ? (const void*)p.res : (const void*)p.out, has_res ? p.out_bytes : 0u);
     const int PIX = MODE == 0 ? PQ : HW;
+    // loads first, in batches (one wait per batch), then arithmetic and stores: a load -> wait -> store chain per element made the
+    // first version of this epilogue cost more than the whole k-loop on the small DPTN layers
+    float sh[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[i][r] = 0.f;
+    if (has_shift) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sh[i][r] = bloadf(rsh, (unsigned)(mrow0 + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nn = n0 + wn * WTN + j * 32 + l32;
@@ -517,17 +581,27 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
                 ob = (unsigned)((((int64_t)img * p.M + mrow0) * HW + (ah + p.SH * hc) * p.W + aw + p.SW * wc) * 4);
             }
         }
+        unsigned off[TM][16];
+        float rv[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
-                const unsigned off = (mrow0 + mo < p.M) ? ob + (unsigned)(mo * PIX) * 4u : OOB;
-                float v = acc[i][j][r] * scale + bloadf(rsh, (unsigned)(mrow0 + mo) * 4u);
-                if (p.res) v += bloadf(rr, off);
-                v = rg_apply_act(v, p.act, p.slope);
-                bstoref(ro, off, v);
+                off[i][r] = (mrow0 + mo < p.M) ? ob + (unsigned)(mo * PIX) * 4u : OOB;
+                rv[i][r] = 0.f;
             }
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[i][r] = bloadf(rr, off[i][r]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bstoref(ro, off[i][r], rg_apply_act(acc[i][j][r] * scale + sh[i][r] + rv[i][r], p.act, p.slope));
     }
 }
 
@@ -581,17 +655,28 @@ static int check_geom(const char* op, int N, int C, int H, int W, int K, int KH,
 
 static int pad16(int v) { return (v + 15) / 16 * 16; }
 
-#define RG_F8_LAUNCH(MODE_, GRID_)                                                                                         \
+#define RG_F8_LAUNCH_NB(MODE_, GRID_, NB_)                                                                                  \
     do {                                                                                                                   \
         if (bm == 128) {                                                                                                   \
-            if (fa == 0 && fb == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 0, 0>), GRID_, dim3(NT), 0, stream, p);  \
-            else if (fa == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 0, 1>), GRID_, dim3(NT), 0, stream, p);        \
-            else hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 1, 0>), GRID_, dim3(NT), 0, stream, p);                     \
+            if (fa == 0 && fb == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 0, 0, NB_>), GRID_, dim3(NT), 0, stream, p);  \
+            else if (fa == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 0, 1, NB_>), GRID_, dim3(NT), 0, stream, p);        \
+            else hipLaunchKernelGGL((conv_f8_kernel<MODE_, 128, 1, 0, NB_>), GRID_, dim3(NT), 0, stream, p);                     \
         } else {                                                                                                           \
-            if (fa == 0 && fb == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 0, 0>), GRID_, dim3(NT), 0, stream, p);   \
-            else if (fa == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 0, 1>), GRID_, dim3(NT), 0, stream, p);         \
-            else hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 1, 0>), GRID_, dim3(NT), 0, stream, p);                      \
+            if (fa == 0 && fb == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 0, 0, NB_>), GRID_, dim3(NT), 0, stream, p);   \
+            else if (fa == 0) hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 0, 1, NB_>), GRID_, dim3(NT), 0, stream, p);         \
+            else hipLaunchKernelGGL((conv_f8_kernel<MODE_, 64, 1, 0, NB_>), GRID_, dim3(NT), 0, stream, p);                      \
         }                                                                                                                  \
+    } while (0)
+
+// RG_F8_NB=2 selects the register-staged two-buffer loop (the first version; kept for A/B measurements), default the 4-deep DMA ring
+static int f8_ring() {
+    static const int nb = getenv("RG_F8_NB") ? atoi(getenv("RG_F8_NB")) : 4;
+    return nb == 2 ? 2 : 4;
+}
+#define RG_F8_LAUNCH(MODE_, GRID_)                      \
+    do {                                                \
+        if (f8_ring() == 2) RG_F8_LAUNCH_NB(MODE_, GRID_, 2); \
+        else RG_F8_LAUNCH_NB(MODE_, GRID_, 4);          \
     } while (0)
 
 }  // namespace
@@ -664,7 +749,8 @@ extern "C" int rg_conv2d_f8_fwd(const void* xq, const void* wq, const float* sx,
     p.Cq = Cp / 16;
     p.Kc = KH * KW * p.Cq;
     p.d_cq = make_fastdiv(p.Cq);
-    const int bm = K <= 64 ? 64 : 128, fa = 0, fb = fmt_x;
+    static const int bm_env = getenv("RG_F8_BM") ? atoi(getenv("RG_F8_BM")) : 0;
+    const int bm = bm_env ? bm_env : (K <= 64 ? 64 : 128), fa = 0, fb = fmt_x;
     p.m_tiles = rg::cdiv(K, bm);
     p.n_tiles = rg::cdiv(p.Ng, BN);
     rg::ProfScope prof(rg::FAM_CONV_F8, stream, 2.0 * K * (double)p.Ng * C * KH * KW,
@@ -695,7 +781,8 @@ extern "C" int rg_conv2d_f8_dgrad(const void* dyq, const void* wq_t, const float
     p.M = C;
     p.Cq = Kp / 16;
     p.d_cq = make_fastdiv(p.Cq);
-    const int bm = C <= 64 ? 64 : 128, fa = 0, fb = fmt_dy;
+    static const int bm_env = getenv("RG_F8_BM") ? atoi(getenv("RG_F8_BM")) : 0;
+    const int bm = bm_env ? bm_env : (C <= 64 ? 64 : 128), fa = 0, fb = fmt_dy;
     p.m_tiles = rg::cdiv(C, bm);
     int nt_max = 0;
     double flops = 0.0;
