@@ -43,32 +43,38 @@ class DPTNModel(BaseModel):
     def name(self):
         return 'DPTNModel'
 
+    # command-line surface of the reference object (DPTN_model.py:18-42): flag -> (argparse keywords); same names, types and
+    # defaults, so option files and scripts written for the reference parse unchanged.  The last three are this build's.
+    _FLAGS = {
+        'init_type': dict(type=str, default='orthogonal', help='initial type'),
+        'use_spect_g': dict(action='store_false', help='use spectual normalization in generator'),
+        'use_spect_d': dict(action='store_false', help='use spectual normalization in generator'),
+        'use_coord': dict(action='store_true', help='use coordconv'),
+        'lambda_style': dict(type=float, default=500, help='weight for the VGG19 style loss'),
+        'lambda_content': dict(type=float, default=0.5, help='weight for the VGG19 content loss'),
+        'layers_g': dict(type=int, default=3, help='number of layers in G'),
+        'save_input': dict(action='store_true', help='whether save the input images when testing'),
+        'num_blocks': dict(type=int, default=3, help='number of resblocks'),
+        'affine': dict(action='store_true', default=True, help='affine in PTM'),
+        'nhead': dict(type=int, default=2, help='number of heads in PTM'),
+        'num_CABs': dict(type=int, default=2, help='number of CABs in PTM'),
+        'num_TTBs': dict(type=int, default=2, help='number of CABs in PTM'),
+        'ratio_g2d': dict(type=float, default=0.1, help='learning rate ratio G to D'),
+        'lambda_rec': dict(type=float, default=2.0, help='weight for image reconstruction loss'),
+        'lambda_g': dict(type=float, default=5.0, help='weight for generation loss'),
+        't_s_ratio': dict(type=float, default=0.8, help='loss ratio between dual tasks'),
+        'dis_layers': dict(type=int, default=3, help='number of layers in D'),
+        'vgg_weights': dict(type=str, default='', help='local torchvision vgg19 state_dict (.pth)'),
+        'conv_dtype': dict(type=str, default='fp32', help='fp32 | fp8: MFMA family of the convolutions'),
+        'f8_scaling': dict(type=str, default='delayed', help='delayed | jit: per-tensor fp8 scale policy'),
+    }
+    _DEFAULT_OVERRIDES = dict(use_spect_g=False, use_spect_d=True)
+
     @staticmethod
     def modify_options(parser, is_train=True):
-        """Add new options and rewrite default values for existing options (DPTN_model.py:18-42)"""
-        parser.add_argument('--init_type', type=str, default='orthogonal', help='initial type')
-        parser.add_argument('--use_spect_g', action='store_false', help='use spectual normalization in generator')
-        parser.add_argument('--use_spect_d', action='store_false', help='use spectual normalization in generator')
-        parser.add_argument('--use_coord', action='store_true', help='use coordconv')
-        parser.add_argument('--lambda_style', type=float, default=500, help='weight for the VGG19 style loss')
-        parser.add_argument('--lambda_content', type=float, default=0.5, help='weight for the VGG19 content loss')
-        parser.add_argument('--layers_g', type=int, default=3, help='number of layers in G')
-        parser.add_argument('--save_input', action='store_true', help="whether save the input images when testing")
-        parser.add_argument('--num_blocks', type=int, default=3, help="number of resblocks")
-        parser.add_argument('--affine', action='store_true', default=True, help="affine in PTM")
-        parser.add_argument('--nhead', type=int, default=2, help="number of heads in PTM")
-        parser.add_argument('--num_CABs', type=int, default=2, help="number of CABs in PTM")
-        parser.add_argument('--num_TTBs', type=int, default=2, help="number of CABs in PTM")
-        parser.add_argument('--ratio_g2d', type=float, default=0.1, help='learning rate ratio G to D')
-        parser.add_argument('--lambda_rec', type=float, default=2.0, help='weight for image reconstruction loss')
-        parser.add_argument('--lambda_g', type=float, default=5.0, help='weight for generation loss')
-        parser.add_argument('--t_s_ratio', type=float, default=0.8, help='loss ratio between dual tasks')
-        parser.add_argument('--dis_layers', type=int, default=3, help='number of layers in D')
-        parser.add_argument('--vgg_weights', type=str, default='', help='local torchvision vgg19 state_dict (.pth)')
-        parser.add_argument('--conv_dtype', type=str, default='fp32', help='fp32 | fp8: MFMA family of the convolutions')
-        parser.add_argument('--f8_scaling', type=str, default='delayed', help='delayed | jit: per-tensor fp8 scale policy')
-        parser.set_defaults(use_spect_g=False)
-        parser.set_defaults(use_spect_d=True)
+        for flag, kw in DPTNModel._FLAGS.items():
+            parser.add_argument('--' + flag, **kw)
+        parser.set_defaults(**DPTNModel._DEFAULT_OVERRIDES)
         return parser
 
     def __init__(self, opt):
