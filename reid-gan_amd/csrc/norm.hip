@@ -621,12 +621,14 @@ extern "C" int rg_bn_bwd_reduce(const float* x, const float* dy, const float* y_
 
 // ---- InstanceNorm2d in one launch per direction -----------------------------------------------------------------------
 // An instance (n, c) is HW contiguous floats: <= 32 KB for every map of the dual_gan / FD-GAN networks, so the second and third
-// pass over it hit L1 / L2.  WAVES = 1: one wave per instance (4 instances per workgroup, shuffles only) for small maps;
-// WAVES = 4: one workgroup per instance.  Statistics: mean, then the centred sum of squares (two-pass, biased variance).
-template <int WAVES>
+// pass over it hit L1 / L2.  LANES = 16 / 32 / 64 lanes per instance (several instances per wave for the small maps, shuffles only),
+// 256: one workgroup per instance.  Statistics: mean, then the centred sum of squares (two-pass, biased variance).
+template <int LANES>
 __device__ __forceinline__ float in_reduce(float v, float* red) {
-    v = rg_wave_sum(v);
-    if (WAVES == 1) return v;
+    // LANES <= 64: butterfly inside the aligned lane group (several instances share a wave); 256: the whole workgroup
+#pragma unroll
+    for (int off = (LANES < 64 ? LANES : 64) / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (LANES <= 64) return v;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wid] = v;
@@ -634,17 +636,17 @@ __device__ __forceinline__ float in_reduce(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int WAVES>
+template <int LANES>
 __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ res,
                                                            float* __restrict__ y, float* __restrict__ mean_out,
                                                            float* __restrict__ invstd_out, int NC, int C, int HW, float eps,
                                                            int act, float slope) {
     __shared__ float red[4];
-    const int inst = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (inst >= NC) return;                                   // WAVES == 1 only (whole waves leave; no barrier in that mode)
-    const int t = WAVES == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    constexpr int T = WAVES * 64;
+    const int inst = (int)blockIdx.x * (256 / LANES) + (int)threadIdx.x / LANES;
+    if (inst >= NC) return;                                   // whole lane groups leave (LANES == 256: never taken, grid = NC)
+    const int t = (int)threadIdx.x % LANES;
+    constexpr int T = LANES;
     const int64_t base = (int64_t)inst * HW;
     const float* xp = x + base;
     const bool vec = (HW & 3) == 0;
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
     } else {
         for (int i = t; i < HW; i += T) s += xp[i];
     }
-    const float mu = in_reduce<WAVES>(s, red) / (float)HW;
+    const float mu = in_reduce<LANES>(s, red) / (float)HW;
     float q = 0.f;
     if (vec) {
         for (int i = t; i < nv; i += T) {
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
             q += a * a;
         }
     }
-    const float is = rsqrtf(in_reduce<WAVES>(q, red) / (float)HW + eps);
+    const float is = rsqrtf(in_reduce<LANES>(q, red) / (float)HW + eps);
     if (t == 0) {
         mean_out[inst] = mu;
         invstd_out[inst] = is;
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
 
 // g = dy * act'(y); s1 = sum g, s2 = sum g * xhat (written per instance for the affine gradients);
 // dx = gamma * invstd * (g - s1 / HW - xhat * s2 / HW); dres = g
-template <int WAVES>
+template <int LANES>
 __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ yact, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -715,10 +717,10 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
                                                            float* __restrict__ sum_dx, int NC, int C, int HW, int act,
                                                            float slope) {
     __shared__ float red[4];
-    const int inst = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int inst = (int)blockIdx.x * (256 / LANES) + (int)threadIdx.x / LANES;
     if (inst >= NC) return;
-    const int t = WAVES == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    constexpr int T = WAVES * 64;
+    const int t = (int)threadIdx.x % LANES;
+    constexpr int T = LANES;
     const int64_t base = (int64_t)inst * HW;
     const float* xp = x + base;
     const float* gp = dy + base;
@@ -747,8 +749,8 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
             s2 += g * (xp[i] - mu);
         }
     }
-    s1 = in_reduce<WAVES>(s1, red);
-    s2 = in_reduce<WAVES>(s2, red) * is;
+    s1 = in_reduce<LANES>(s1, red);
+    s2 = in_reduce<LANES>(s2, red) * is;
     if (t == 0) {
         sum_dy[inst] = s1;
         sum_dy_xhat[inst] = s2;
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
         }
     }
     if (sum_dx) {                                                // uniform: the bias gradient of the convolution in front
-        sdx = in_reduce<WAVES>(sdx, red);
+        sdx = in_reduce<LANES>(sdx, red);
         if (t == 0) sum_dx[inst] = sdx;
     }
 }
@@ -1019,6 +1021,15 @@ extern "C" int rg_bn_train_bwd_fused(const float* x, const float* dy, const floa
     return rg::check_launch("rg_bn_train_bwd_fused");
 }
 
+// lanes per instance: at least ~2 load units (float4 when HW % 4 == 0) per lane, one workgroup above 2048 elements
+static int in_lanes(int HW) {
+    if (HW > 2048) return 256;
+    const int units = (HW & 3) ? HW : HW >> 2;
+    if (units <= 32) return 16;
+    if (units <= 64) return 32;
+    return 64;
+}
+
 // InstanceNorm2d forward: y = act(gamma[c] * (x - mean[n,c]) * invstd[n,c] + beta[c] + residual); mean / invstd [N*C] are kept for
 // the backward.  One launch.
 extern "C" int rg_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
@@ -1028,12 +1039,16 @@ extern "C" int rg_instnorm_fwd(const float* x, const float* gamma, const float* 
     RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_fwd: N*C exceeds 2^31");
     const int NC = N * C;
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * (double)NC * HW);
-    if (HW <= 2048)
-        hipLaunchKernelGGL(instnorm_fwd_kernel<1>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, gamma, beta, residual, y, mean,
-                           invstd, NC, C, HW, eps, act, slope);
-    else
-        hipLaunchKernelGGL(instnorm_fwd_kernel<4>, dim3(NC), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd, NC,
-                           C, HW, eps, act, slope);
+    switch (in_lanes(HW)) {
+        case 16: hipLaunchKernelGGL(instnorm_fwd_kernel<16>, dim3(rg::cdiv(NC, 16)), dim3(256), 0, stream, x, gamma, beta, residual, y,
+                                    mean, invstd, NC, C, HW, eps, act, slope); break;
+        case 32: hipLaunchKernelGGL(instnorm_fwd_kernel<32>, dim3(rg::cdiv(NC, 8)), dim3(256), 0, stream, x, gamma, beta, residual, y,
+                                    mean, invstd, NC, C, HW, eps, act, slope); break;
+        case 64: hipLaunchKernelGGL(instnorm_fwd_kernel<64>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, gamma, beta, residual, y,
+                                    mean, invstd, NC, C, HW, eps, act, slope); break;
+        default: hipLaunchKernelGGL(instnorm_fwd_kernel<256>, dim3(NC), dim3(256), 0, stream, x, gamma, beta, residual, y, mean,
+                                    invstd, NC, C, HW, eps, act, slope);
+    }
     return rg::check_launch("rg_instnorm_fwd");
 }
 
@@ -1048,12 +1063,16 @@ extern "C" int rg_instnorm_bwd(const float* x, const float* dy, const float* y_a
     RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_bwd: N*C exceeds 2^31");
     const int NC = N * C;
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, ((act ? 12.0 : 8.0) + (dx ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)) * (double)NC * HW);
-    if (HW <= 2048)
-        hipLaunchKernelGGL(instnorm_bwd_kernel<1>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma,
-                           dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope);
-    else
-        hipLaunchKernelGGL(instnorm_bwd_kernel<4>, dim3(NC), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres,
-                           sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope);
+    switch (in_lanes(HW)) {
+        case 16: hipLaunchKernelGGL(instnorm_bwd_kernel<16>, dim3(rg::cdiv(NC, 16)), dim3(256), 0, stream, x, dy, y_act, mean, invstd,
+                                    gamma, dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope); break;
+        case 32: hipLaunchKernelGGL(instnorm_bwd_kernel<32>, dim3(rg::cdiv(NC, 8)), dim3(256), 0, stream, x, dy, y_act, mean, invstd,
+                                    gamma, dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope); break;
+        case 64: hipLaunchKernelGGL(instnorm_bwd_kernel<64>, dim3(rg::cdiv(NC, 4)), dim3(256), 0, stream, x, dy, y_act, mean, invstd,
+                                    gamma, dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope); break;
+        default: hipLaunchKernelGGL(instnorm_bwd_kernel<256>, dim3(NC), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx,
+                                    dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope);
+    }
     return rg::check_launch("rg_instnorm_bwd");
 }
 

@@ -648,7 +648,9 @@ def test_dgrad_rowsum(dev, case):
                                               ((2, 16, 32, 16), True, "none"),      # 512: one wave, float4
                                               ((2, 6, 64, 48), True, "relu"),       # 3072: one workgroup per instance, float4
                                               ((2, 3, 51, 43), False, "none"),      # 2193: one workgroup, scalar loads
-                                              ((4, 8, 1, 50), False, "leaky")])     # token maps [B, C, L]
+                                              ((4, 8, 1, 50), False, "leaky"),      # token maps [B, C, L]
+                                              ((3, 7, 16, 8), True, "leaky"),       # 128 elements: 16 lanes per instance, 4 per wave
+                                              ((5, 9, 3, 3), True, "none")])        # 9 elements, scalar loads, ragged instance count
 def test_instance_norm_single_launch(dev, shape, affine, act):
     """rg_instnorm_fwd / rg_instnorm_bwd against torch's instance_norm in fp64: output, statistics, dx, residual gradient, the
     per-instance sums behind dgamma / dbeta, and the per-instance sums of dx (bias gradient of the convolution in front)."""
