@@ -311,7 +311,7 @@ __device__ __forceinline__ floatx16 mfma8(int8v a, int8v b, floatx16 c) {
 
 __device__ __forceinline__ unsigned lds_off(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row >> 2)) & 3) * 16u; }
 
-// MODE 0 forward, 1 data gradient (blockIdx.z = class), 2 weight gradient (blockIdx.z = split)
+// MODE 0 forward, 1 data gradient (class from the workgroup id, see below), 2 weight gradient (blockIdx.z = split)
 // NB = 2: operands staged through registers (global -> VGPR -> ds_write), two LDS buffers, prefetch distance one k-tile.
 // NB > 2: LDS-DMA ring (buffer_load ... lds, 16 bytes per lane): no staging registers, NB - 1 k-tiles in flight per workgroup.  A
 //         k-tile is only 64 reduction bytes = one MFMA step per 32x32 block (~100 ns of matrix work per workgroup), so the loop is
@@ -327,18 +327,35 @@ __global__ __launch_bounds__(NT) void conv_f8_kernel(const F8P p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const F8Class& cl = p.cls[MODE == 1 ? blockIdx.z : 0];
+    // Data gradient with stride: the SH*SW parity classes of one tile write INTERLEAVED pixels of the same output rows (every
+    // second float).  Their workgroups are laid out back to back on one XCD (id % 8 = XCD, classes fastest), so those half-written
+    // lines meet in one L2 and leave it whole; launched class by class (grid z) the same bytes cost twice the HBM write time.
+    int cls_idx = 0, tile_pre = -1;
+    if (MODE == 1) {
+        const int ncls = p.SH * p.SW;
+        if (ncls > 1) {
+            const int slots = p.m_tiles * p.n_tiles;           // n_tiles = the largest class
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+            cls_idx = k % ncls;
+            const int sl = k / ncls;
+            const int q = slots >> 3, r = slots & 7;
+            if (sl >= q + (xcd < r ? 1 : 0)) return;
+            tile_pre = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sl;
+        }
+    }
+    const F8Class& cl = p.cls[cls_idx];
     const int ntl = MODE == 1 ? cl.ntiles : p.n_tiles;
     const int nwg = p.m_tiles * ntl;
-    if ((int)blockIdx.x >= nwg) return;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    if (tile_pre < 0 && (int)blockIdx.x >= nwg) return;
+    const int tile = tile_pre >= 0 ? tile_pre : xcd_remap(blockIdx.x, nwg);
+    if (tile >= nwg) return;
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int Ng = MODE == 1 ? cl.Ngc : p.Ng;
     const int Kc = MODE == 1 ? cl.Kc : p.Kc;
     const rsrc_t ra = make_rsrc(p.A, p.a_bytes), rb = make_rsrc(p.B, p.b_bytes);
     const int RS = p.KH * p.KW, HW = p.H * p.W, PQ = p.P * p.Q;
-    const int ah = MODE == 1 ? (int)blockIdx.z / p.SW : 0, aw = MODE == 1 ? (int)blockIdx.z % p.SW : 0;
+    const int ah = MODE == 1 ? cls_idx / p.SW : 0, aw = MODE == 1 ? cls_idx % p.SW : 0;
 
     // ---- per-thread staging rows: chunk (tid & 3) of rows (tid >> 2) + 64 i ----
     const int ch = tid & 3, srow = tid >> 2;
@@ -807,7 +824,8 @@ extern "C" int rg_conv2d_f8_dgrad(const void* dyq, const void* wq_t, const float
     p.Ng = 0; p.Kc = 0; p.n_tiles = nt_max;
     rg::ProfScope prof(rg::FAM_CONV_F8, stream, flops,
                        (double)N * P * Q * Kp + (double)C * KH * KW * Kp + 4.0 * N * C * H * W);
-    const dim3 grid(p.m_tiles * nt_max, 1, SH * SW);
+    const int slots = p.m_tiles * nt_max;
+    const dim3 grid(SH * SW > 1 ? (unsigned)(8 * ((slots >> 3) + 1) * SH * SW) : (unsigned)slots, 1, 1);
     RG_F8_LAUNCH(1, grid);
     return rg::check_launch("rg_conv2d_f8_dgrad");
 }
