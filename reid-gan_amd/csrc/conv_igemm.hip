@@ -544,6 +544,172 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 with TAP REUSE (forward, and the data gradient of such a layer, which is the same convolution with
+// the filter taps flipped and the channel roles swapped).
+// The generic kernels gather the pixel operand once per filter tap: nine L2 -> LDS passes over the same activations.  With a
+// 128-pixel tile that is 12 KB of operands per 0.26 MFLOP, and at ~6 TB/s of L2 delivery the 64 / 128-channel layers of the trunk
+// are bound by that traffic, not by the matrix pipe.  Here the reduction runs channel-block outer, tap inner: for every block of
+// 16 reduction channels the workgroup loads ONE halo tile of the activations — its 128 output pixels (whole rows of one image, or
+// whole small images) plus the one-pixel border, zero outside the image — and all nine taps read their pixel operand from that
+// tile at a constant offset ((r-1) * (W+2) + (s-1)); only the filter operand (16 x BM floats) is fetched per tap.  Pixel-operand
+// traffic drops 5-6 x and each barrier interval holds the same 8 MFMA k-steps as before but only the filter loads.
+// Requirements (checked on the host): W in {4..64} a power of two, tile rows dividing H or whole images per tile, reduction
+// channels % 16 == 0, filters in the [K][9][C] copy.
+// ---------------------------------------------------------------------------------------------
+struct HaloP {
+    ConvP c;             // x: input tensor of the convolution being computed (fwd: x, dgrad: dy); w: [K][9][C] filters; y: output
+    int Cred;            // channels of that input tensor (the reduction): fwd C, dgrad K
+    int HP, Wh, slab;    // halo positions per tile, halo row length W + 2, positions per image of the tile (rows + 2) * Wh
+    int cblocks, cb_per_split;
+    FastDiv d_hp, d_slab, d_wh, d_hw, d_w;
+};
+
+template <int BM, bool DGRAD, int NH>
+__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const HaloP hp) {
+    using T = Tile<BM, 128, 2, 2>;
+    const ConvP& p = hp.c;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
+    __shared__ __attribute__((aligned(16))) float Hs[2][NH * NT];     // [16 channels][HP positions], flat
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
+    const int m0 = mt * BM, n0 = nt * 128;
+    const int split = blockIdx.y;
+    const int HW = p.H * p.W, HP = hp.HP, Wh = hp.Wh;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+
+    // tile origin: 128 % W == 0, so a tile starts at the beginning of a row (and covers whole rows / whole images)
+    const int img0 = fdiv(n0, hp.d_hw);
+    const int h0 = fdiv(n0 - img0 * HW, hp.d_w);
+
+    // ---- pixel-operand positions of this lane inside the halo tile (two 32-pixel column blocks of the wave) ----
+    int pos[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int pl = wn * T::WTN + j * 32 + l32;
+        const int il = fdiv(pl, hp.d_hw);                      // 0 when the tile lies inside one image (H*W >= 128)
+        const int rem = pl - il * HW;
+        const int hl = fdiv(rem, hp.d_w);
+        pos[j] = il * hp.slab + (hl + 1) * Wh + (rem - hl * p.W) + 1;
+    }
+
+    // ---- halo loader: element f = tid + 256 i of [16][HP]; byte offset of channel block 0, OOB outside the image ----
+    unsigned hoff[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int f = tid + NT * i;
+        const int ch = fdiv(f, hp.d_hp);
+        const int ps = f - ch * HP;
+        const int il = fdiv(ps, hp.d_slab);
+        const int r2 = ps - il * hp.slab;
+        const int hh = fdiv(r2, hp.d_wh);
+        const int ww = r2 - hh * Wh - 1;
+        const int img = img0 + il, h = h0 + hh - 1;
+        const bool ok = ch < BK && img < p.N && (unsigned)h < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
+        hoff[i] = ok ? (unsigned)((((int64_t)img * hp.Cred + ch) * p.H + h) * p.W + ww) * 4u : OOB;
+    }
+    const unsigned cbstride = (unsigned)(BK * HW) * 4u;        // bytes between channel blocks of the input tensor
+
+    // ---- filter-operand loader ----
+    constexpr int NA = BM / 64;                                // float4 per thread and tile (BM * 16 / 4 / 256)
+    unsigned aoff[NA];
+    int arow[NA], akq[NA];                                     // fwd: (row m, k quad); dgrad: (k row, m quad)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int v = tid + NT * i;
+        if (!DGRAD) {
+            arow[i] = v >> 2;
+            akq[i] = (v & 3) * 4;
+            aoff[i] = (m0 + arow[i] < p.M) ? (unsigned)(((int64_t)(m0 + arow[i]) * 9 * hp.Cred + akq[i]) * 4) : OOB;
+        } else {
+            arow[i] = v / (BM / 4);
+            akq[i] = (v - arow[i] * (BM / 4)) * 4;
+            aoff[i] = (m0 + akq[i] < p.M) ? (unsigned)(((int64_t)arow[i] * 9 * p.M + m0 + akq[i]) * 4) : OOB;
+        }
+    }
+    float4 ra[NA];
+    float hv[NH];
+    floatx16 acc[T::TM][T::TN];
+    zero_acc<T>(acc);
+
+    auto load_a = [&](int cb, int t) {
+        // fwd: w[m][t][cb*16 + kq..]; dgrad: w[cb*16 + kk][8 - t][m..] (the flipped tap of the transposed filter)
+        const unsigned kb4 = DGRAD ? (unsigned)(((int64_t)cb * BK * 9 + (8 - t)) * p.M) * 4u
+                                   : (unsigned)(t * hp.Cred + cb * BK) * 4u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = bload4(rw, aoff[i] == OOB ? OOB : aoff[i] + kb4);
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!DGRAD) {
+                As[buf][akq[i] + 0][arow[i]] = ra[i].x;
+                As[buf][akq[i] + 1][arow[i]] = ra[i].y;
+                As[buf][akq[i] + 2][arow[i]] = ra[i].z;
+                As[buf][akq[i] + 3][arow[i]] = ra[i].w;
+            } else {
+                *reinterpret_cast<float4*>(&As[buf][arow[i]][akq[i]]) = ra[i];
+            }
+        }
+    };
+    auto load_h = [&](int cb) {
+        const unsigned o = (unsigned)cb * cbstride;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) hv[i] = bload(rx, hoff[i] == OOB ? OOB : hoff[i] + o);
+    };
+    auto store_h = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) Hs[buf][tid + NT * i] = hv[i];
+    };
+
+    const int cb_begin = split * hp.cb_per_split;
+    int cb_end = cb_begin + hp.cb_per_split;
+    if (cb_end > hp.cblocks) cb_end = hp.cblocks;
+    if (cb_begin < cb_end) {
+        load_h(cb_begin);
+        load_a(cb_begin, 0);
+        store_h(0);
+        store_a(0);
+    }
+    __syncthreads();
+    int ab = 0, hb = 0;
+    for (int cb = cb_begin; cb < cb_end; ++cb) {
+        const bool more_cb = cb + 1 < cb_end;
+        for (int t = 0; t < 9; ++t) {
+            const bool last = !more_cb && t == 8;
+            if (t == 0 && more_cb) load_h(cb + 1);             // lands during the nine taps of this block
+            if (!last) load_a(t == 8 ? cb + 1 : cb, t == 8 ? 0 : t + 1);
+            const int r = (t * 11) >> 5;                       // t / 3 for t < 9
+            const int toff = (r - 1) * Wh + (t - 3 * r - 1);
+            const float* hsb = Hs[hb];
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                const int k = 2 * ks + kh;
+                float a[T::TM], b[T::TN];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) a[i] = As[ab][k][wm * T::WTM + i * 32 + l32];
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) b[j] = hsb[k * HP + pos[j] + toff];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (!last) store_a(ab ^ 1);
+            if (t == 8 && more_cb) store_h(hb ^ 1);
+            __syncthreads();
+            ab ^= 1;
+        }
+        hb ^= 1;
+    }
+    store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, p.Ng, HW, hp.d_hw, split, nt * 2 + wn);
+}
+
+// ---------------------------------------------------------------------------------------------
 // data gradient (also the forward of ConvTranspose2d), one GEMM per stride-parity class.
 // MODE 0: weights [K][C][KH][KW], reduction order (ko, tap), scalar loads (any geometry)
 // MODE 1: weights [K][KH*KW][C] (== the original tensor for 1x1), tap-major order k' = tap*K + ko, K % 16 == 0 and
@@ -1453,6 +1619,89 @@ static unsigned finish_grid(int64_t n) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+// ---- tap-reuse kernel (conv3x3_halo_kernel): geometry test, plan, launch ----
+static bool halo_enabled() {
+    static const int env = getenv("RG_CONV_HALO") ? atoi(getenv("RG_CONV_HALO")) : 1;
+    return env != 0;
+}
+static bool halo_geom(int H, int W, int* HP, int* Wh, int* slab) {
+    if (W < 4 || W > 64 || (W & (W - 1))) return false;
+    const int R = 128 / W;                      // rows of a 128-pixel tile
+    int rows, imgs;
+    if (R <= H) {
+        if (H % R) return false;
+        rows = R;
+        imgs = 1;
+    } else {
+        if (R % H) return false;                // whole images per tile
+        rows = H;
+        imgs = R / H;
+    }
+    *Wh = W + 2;
+    *slab = (rows + 2) * (W + 2);
+    *HP = imgs * *slab;
+    return *HP <= 288;
+}
+struct HaloPlan {
+    int bm, m_tiles, n_tiles, splits, per;
+};
+static HaloPlan halo_plan(int M, int64_t Ng, int Cred) {
+    HaloPlan pl;
+    pl.bm = M <= 64 ? 64 : 128;
+    pl.m_tiles = rg::cdiv(M, pl.bm);
+    pl.n_tiles = (int)rg::cdiv64(Ng, 128);
+    const int cblocks = Cred / BK;
+    const int64_t tiles = (int64_t)pl.m_tiles * pl.n_tiles;
+    int64_t want = tiles >= 384 ? 1 : rg::cdiv64(512, tiles);       // ~2 workgroups per CU
+    if (want > cblocks / 2) want = cblocks / 2;                     // >= 2 channel blocks (18 k-tiles) per split
+    if (want > 16) want = 16;
+    if (want < 1) want = 1;
+    while (want > 1 && want * (int64_t)M * Ng * 4 >= (1ll << 31)) --want;
+    pl.per = (int)rg::cdiv64(cblocks, want);
+    pl.splits = rg::cdiv(cblocks, pl.per);
+    return pl;
+}
+static size_t halo_workspace(int M, int64_t Ng, int Cred) {
+    const HaloPlan pl = halo_plan(M, Ng, Cred);
+    return pl.splits > 1 ? (size_t)pl.splits * M * (size_t)Ng * sizeof(float) : 0;
+}
+// p: x / w (krsc) / y / ep / M / Ng / byte sizes filled by the caller; returns the launch status
+template <bool DGRAD>
+static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, void* workspace, hipStream_t stream, const char* op) {
+    HaloP hp;
+    int HPv, Wh, slab;
+    halo_geom(H, W, &HPv, &Wh, &slab);
+    p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
+    p.splits = pl.splits;
+    p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    p.partial_bytes = pl.splits > 1 ? (unsigned)((size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float)) : 0u;
+    hp.c = p;
+    hp.Cred = Cred;
+    hp.HP = HPv; hp.Wh = Wh; hp.slab = slab;
+    hp.cblocks = Cred / BK;
+    hp.cb_per_split = pl.per;
+    hp.d_hp = make_fastdiv(HPv);
+    hp.d_slab = make_fastdiv(slab);
+    hp.d_wh = make_fastdiv(Wh);
+    hp.d_hw = make_fastdiv(H * W);
+    hp.d_w = make_fastdiv(W);
+    const dim3 grid(pl.m_tiles * pl.n_tiles, pl.splits, 1);
+    const bool small = 16 * HPv <= 13 * NT;
+    if (pl.bm == 128) {
+        if (small) hipLaunchKernelGGL((conv3x3_halo_kernel<128, DGRAD, 13>), grid, dim3(NT), 0, stream, hp);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<128, DGRAD, 18>), grid, dim3(NT), 0, stream, hp);
+    } else {
+        if (small) hipLaunchKernelGGL((conv3x3_halo_kernel<64, DGRAD, 13>), grid, dim3(NT), 0, stream, hp);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<64, DGRAD, 18>), grid, dim3(NT), 0, stream, hp);
+    }
+    if (pl.splits > 1) {
+        if (int e = rg::check_launch(op)) return e;
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * p.Ng)), dim3(256), 0, stream, p.partial, p.y,
+                           p.M, p.Ng, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+    }
+    return rg::check_launch(op);
+}
+
 }  // namespace
 
 #define RG_FWD_LAUNCH(BM_, BN_, WM_, WN_)                                                                             \
@@ -1519,7 +1768,13 @@ extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, i
         return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)K * (size_t)Ng * sizeof(float);
     }
     const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
-    return pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
+    size_t need = pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
+    int hpv, wh, slab;
+    if (KH == 3 && KW == 3 && C % BK == 0 && K >= 64 && halo_enabled() && halo_geom(P, Q, &hpv, &wh, &slab)) {   // stride 1 / pad 1: P x Q = H x W
+        const size_t hn = halo_workspace(K, (int64_t)N * P * Q, C);
+        if (hn > need) need = hn;
+    }
+    return need;
 }
 
 // w_krsc (optional): weights re-laid out as [K][KH*KW][C] (rg_weights_to_krsc); with C % 16 == 0 it selects the
@@ -1552,6 +1807,23 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)K * p.Ng)), dim3(256), 0, stream,
                                t.partial, y, K, p.Ng, P * Q, p.d_pq, slices, p.ep);
             return rg::check_launch("rg_conv2d_fwd(thin finish)");
+        }
+    }
+    {
+        int hpv, wh, slab;
+        // (fewer than 64 output rows: the 32 x 256 tile of the generic kernel wastes less than a half-empty 64-row tile)
+        if (KH == 3 && KW == 3 && SH == 1 && SW == 1 && PH == 1 && PW == 1 && C % BK == 0 && K >= 64 && w_krsc &&
+            ((reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && halo_enabled() &&
+            halo_geom(H, W, &hpv, &wh, &slab)) {
+            HaloPlan hpl = halo_plan(p.M, p.Ng, C);
+            const size_t need = hpl.splits > 1 ? (size_t)hpl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
+            if (need > workspace_bytes || (need && !workspace)) {
+                hpl.splits = 1;
+                hpl.per = C / BK;
+            }
+            p.w = w_krsc;
+            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
+            return halo_launch<false>(p, C, H, W, hpl, workspace, stream, "rg_conv2d_fwd(3x3 tap reuse)");
         }
     }
     const bool is1x1 = KH == 1 && KW == 1;
@@ -1594,7 +1866,13 @@ extern "C" int rg_conv_set_force(int tile, int splits) {
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
     if (SH != 1 || SW != 1) return 0;
     const GemmPlan pl = plan_gemm(C, (int64_t)N * H * W, (int64_t)K * KH * KW, true);
-    return pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
+    size_t need = pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
+    int hpv, wh, slab;
+    if (KH == 3 && KW == 3 && K % BK == 0 && C % 4 == 0 && C >= 64 && halo_enabled() && halo_geom(H, W, &hpv, &wh, &slab)) {
+        const size_t hn = halo_workspace(C, (int64_t)N * H * W, K);
+        if (hn > need) need = hn;
+    }
+    return need;
 }
 
 // w_krsc: the weights re-laid out as [K][KH*KW][C] by rg_weights_to_krsc (may be NULL; for 1x1 filters the
@@ -1676,6 +1954,32 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
         if (is1x1 && one_class && PH == 0 && PW == 0 && ((P * Q) % 4 == 0) && dy_al) mode = 2;
         else if (K % 16 == 0) mode = 1;
         if (mode) p.w = wk;
+    }
+    {
+        int hpv, wh, slab;
+        // (a planning call has no pointers: rg_hip.ops always passes the [K][9][C] copy for such layers)
+        if (one_class && KH == 3 && KW == 3 && PH == 1 && PW == 1 && P == H && Q == W && K % BK == 0 && C % 4 == 0 && C >= 64 &&
+            (dry || (wk && dy_al)) && halo_enabled() && halo_geom(H, W, &hpv, &wh, &slab)) {
+            HaloPlan hpl = halo_plan(p.M, ng_max, K);
+            const size_t need = hpl.splits > 1 ? (size_t)hpl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
+            if (!dry && (need > workspace_bytes || (need && !workspace))) {
+                hpl.splits = 1;
+                hpl.per = K / BK;
+            }
+            const int cols = hpl.splits > 1 ? 0 : hpl.n_tiles * 2;
+            if (dry) {
+                *dry = cols;
+                return RG_OK;
+            }
+            RG_REQUIRE(!rowsum || (cols > 0 && rowsum_cols == cols),
+                       "rg_conv2d_dgrad: rowsum_cols %d does not match this launch (%d; query rg_conv2d_dgrad_rowsum_cols)",
+                       rowsum_cols, cols);
+            p.w = wk;
+            p.Ng = (int)ng_max;
+            p.Kg = K * KH * KW;
+            rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
+            return halo_launch<true>(p, K, H, W, hpl, workspace, stream, "rg_conv2d_dgrad(3x3 tap reuse)");
+        }
     }
     // strided classes: only classes that have filter taps do MFMA work (a 1x1 / stride-2 layer has ONE such class, the
     // others only zero-fill), and their reductions differ — plan on the columns that carry work and their mean depth
