@@ -80,6 +80,7 @@ _PLAIN_INT = {"rg_version", "rg_family_count", "rg_fold_chunk", "rg_bn_slices", 
 class _Lib(object):
     def __init__(self):
         self._dll = None
+        self._native = None
         self.protos = parse_header()
 
     def load(self):
@@ -98,11 +99,42 @@ class _Lib(object):
             fn.restype = _ctype_of(ret) if ret != "void" else None
             fn.argtypes = [_ctype_of(t) for t, _ in args]
         self._dll = dll
+        self._native = self._load_native(dll)
         return self
+
+    def _load_native(self, dll):
+        """the generated CPython binding (csrc/gen_pymod.py): same symbols, ~10 x less call overhead than ctypes.  Optional —
+        without it (or with RG_NATIVE_BIND=0) every call goes through ctypes; either way it is this library that runs."""
+        if os.environ.get("RG_NATIVE_BIND", "1") == "0":
+            return None
+        import glob
+        import importlib.machinery
+        import importlib.util
+        cands = glob.glob(os.path.join(PKG_ROOT, "lib", "_rg_native*.so"))
+        if not cands:
+            return None
+        try:
+            loader = importlib.machinery.ExtensionFileLoader("_rg_native", cands[0])
+            spec = importlib.util.spec_from_file_location("_rg_native", cands[0], loader=loader)
+            mod = importlib.util.module_from_spec(spec)
+            loader.exec_module(mod)
+            mod.bind({name: ctypes.cast(getattr(dll, name), ctypes.c_void_p).value for name in self.protos})
+        except Exception as e:                                   # stale build (header changed): say so, keep working
+            import warnings
+            warnings.warn("rg_hip: _rg_native not usable (%s: %s); using ctypes — rebuild with make -C %s"
+                          % (type(e).__name__, e, CSRC_DIR))
+            return None
+        if any(not hasattr(mod, name) for name in self.protos):
+            return None
+        return mod
 
     def __getattr__(self, name):
         if name.startswith("rg_"):
             self.load()
+            if self._native is not None:
+                fn = getattr(self._native, name)                 # status check and error text inside the wrapper
+                setattr(self, name, fn)
+                return fn
             raw = getattr(self._dll, name)
             ret = self.protos[name][0]
             if ret != "int" or name in _PLAIN_INT:
