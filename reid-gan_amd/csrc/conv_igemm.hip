@@ -565,7 +565,7 @@ struct HaloP {
 };
 
 template <int BM, bool DGRAD, int NH>
-__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(const HaloP hp) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void conv3x3_halo_kernel(const HaloP hp) {
     using T = Tile<BM, 128, 2, 2>;
     const ConvP& p = hp.c;
     __shared__ __attribute__((aligned(16))) float As[2][BK][T::LDA];
@@ -1652,7 +1652,8 @@ static HaloPlan halo_plan(int M, int64_t Ng, int Cred) {
     pl.n_tiles = (int)rg::cdiv64(Ng, 128);
     const int cblocks = Cred / BK;
     const int64_t tiles = (int64_t)pl.m_tiles * pl.n_tiles;
-    int64_t want = tiles >= 384 ? 1 : rg::cdiv64(512, tiles);       // ~2 workgroups per CU
+    static const int target = getenv("RG_HALO_WG") ? atoi(getenv("RG_HALO_WG")) : 512;
+    int64_t want = tiles >= (3 * target) / 4 ? 1 : rg::cdiv64(target, tiles);       // ~2 workgroups per CU
     if (want > cblocks / 2) want = cblocks / 2;                     // >= 2 channel blocks (18 k-tiles) per split
     if (want > 16) want = 16;
     if (want < 1) want = 1;
