@@ -146,3 +146,27 @@ def test_dual_gan_registry():
     import pytest
     with pytest.raises(ImportError):
         DM.find_model_using_name("nope")
+
+
+def test_generated_cpython_binding_and_ctypes_fallback():
+    """lib/_rg_native*.so (generated from the header by csrc/gen_pymod.py) serves every entry point with the ctypes binding's
+    conventions — values for queries, RuntimeError + rg_last_error() text for a non-zero status, TypeError for a wrong
+    argument count; RG_NATIVE_BIND=0 runs the same calls through ctypes."""
+    import subprocess
+    import sys
+    lib = L.lib
+    lib.load()
+    assert lib._native is not None, "the generated binding was not built (make -C reid-gan_amd/csrc)"
+    assert all(hasattr(lib._native, n) for n in lib.protos)
+    assert lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32) > 0
+    with pytest.raises(RuntimeError, match="rg_fill failed"):
+        lib.rg_fill(None, 4, 1.0, None)
+    with pytest.raises(TypeError):
+        lib.rg_fill(None, 4)
+    code = ("import sys; sys.path.insert(0, %r); from rg_hip.lib import lib; lib.load(); assert lib._native is None; "
+            "print(lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128), lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32))"
+            % L.PKG_ROOT)
+    env = dict(os.environ, RG_NATIVE_BIND="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout.split()
+    assert [int(v) for v in out] == [lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128),
+                                     lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32)]
