@@ -523,6 +523,9 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+_real_stdout = sys.stdout
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -610,11 +613,15 @@ def main():
         }
         if others is not None:
             out["other_configs"] = others
-        print(json.dumps(out))
-        sys.stdout.flush()
+        print(json.dumps(out), file=_real_stdout)
+        _real_stdout.flush()
     if use_dist:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
+    # stdout carries the ONE JSON line and nothing else: the networks' constructors print like the reference's do ("pooling_type:
+    # gem", parameter counts, "initialize network with ..."), which goes to stderr together with the progress log
+    _real_stdout = sys.stdout
+    sys.stdout = sys.stderr
     main()
