@@ -278,3 +278,28 @@ def test_dptn_step_fp8_declared_tolerance(dev):
             # ad_gen_t = -lambda_g * mean(D(fake)) is a mean of signed values near zero: absolute floor 2e-2 (lambda_g = 5)
             atol = 2e-2 if k == "ad_gen_t" else 1e-3
             assert abs(got[k] - ref[k]) <= 5e-2 * abs(ref[k]) + atol, "step %d %s: fp8 %.5f vs fp32 oracle %.5f" % (step, k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("conv_dtype", ["fp32", "fp8"])
+def test_dptn_steps_are_bit_identical_between_runs(dev, conv_dtype):
+    """three optimizer steps from the same state twice: identical losses, generated images and parameters, bit for bit — the
+    split-K reductions, the integer-atomic amax collection of the fp8 scaling states, the side-stream weight gradients and the
+    batched spectral norm are all order-independent"""
+    def run():
+        torch.manual_seed(5)
+        m, _ = _build(dev, "hinge", conv_dtype=conv_dtype)
+        dd = {k: v.to(dev) for k, v in C.inputs().items()}
+        losses = []
+        for _ in range(3):
+            m.set_input(dd)
+            m.optimize_parameters()
+            losses.append([float(v) for v in m.get_current_errors().values()])
+        torch.cuda.synchronize()
+        params = torch.cat([p.detach().flatten() for p in list(m.net_G.parameters()) + list(m.net_D.parameters())])
+        return losses, m.fake_image_t.detach().clone(), params.clone()
+
+    l1, f1, p1 = run()
+    l2, f2, p2 = run()
+    assert l1 == l2
+    assert torch.equal(f1, f2)
+    assert torch.equal(p1, p2)
