@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """no test may hang the suite: a stuck multi-process rendezvous (or a GPU run-away) fails after a bound instead
+    (pytest-timeout is part of the image; without it the markers are inert)"""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900 if item.get_closest_marker("gpu") else 300))
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

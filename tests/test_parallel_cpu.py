@@ -1,6 +1,7 @@
 """CPU (gloo, world_size 2): the data-parallel plumbing — in-place all-reduce of a gradient arena in chunks, partial
 (per-network) asynchronous launches, 1/world folding into the optimizer's grad_scale, and the rank-ordered
 all-gather used for the ClusterMemory update.  The kernels themselves are GPU-only; this covers the N>1 logic."""
+import datetime
 import os
 import socket
 
@@ -29,7 +30,7 @@ class _FakeOptimizer(object):
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         torch.manual_seed(0)                                  # identical replicas
         net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 11))
@@ -88,6 +89,8 @@ def test_grad_reducer_and_gather_world2():
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()            # this exact child (a rank stuck in a collective must not outlive the test)
         assert p.exitcode == 0
     for rank, err, round2, ok_gather, ws in res:
         assert err < 1e-6, (rank, err)                # mean over the global batch == sum of shard means / world
@@ -128,7 +131,7 @@ def test_arena_views_alias_parameters():
 def _bcast_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         torch.manual_seed(100 + rank)                         # DIFFERENT replicas per rank, as a user script may build them
         net = torch.nn.Sequential(torch.nn.Linear(9, 6), torch.nn.BatchNorm1d(6), torch.nn.Linear(6, 2))
@@ -157,6 +160,8 @@ def test_broadcast_makes_replicas_identical_world2():
     res = sorted(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()            # this exact child (a rank stuck in a collective must not outlive the test)
         assert p.exitcode == 0
     for rank, same_params, rm, nbt, p0, a0 in res:
         assert same_params
@@ -168,7 +173,7 @@ def test_broadcast_makes_replicas_identical_world2():
 def _outside_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         net = torch.nn.Linear(4, 4)
         arena = Arena(list(net.parameters()))
@@ -193,6 +198,8 @@ def test_reducer_raises_on_gradient_outside_arena_world2():
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()            # this exact child (a rank stuck in a collective must not outlive the test)
         assert p.exitcode == 0
     for _, msg in res:
         assert "outside the optimizer's gradient arena" in msg, msg
@@ -211,7 +218,7 @@ def _cpu_cm_update(inputs, targets, features, momentum, hard=False, normalize_ep
 def _cm_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         from rg_hip import ops
         import clustercontrast.models.cm as CMM
@@ -247,6 +254,8 @@ def test_cluster_memory_gather_and_ordered_update_world2():
     res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()            # this exact child (a rank stuck in a collective must not outlive the test)
         assert p.exitcode == 0
     for rank, bank_err, grad_err, _ in res:
         assert bank_err == 0.0, (rank, bank_err)      # every replica applied the same updates in the same order
