@@ -1,9 +1,9 @@
 """CPU (gloo, world_size 2): the data-parallel plumbing — in-place all-reduce of a gradient arena in chunks, partial
 (per-network) asynchronous launches, 1/world folding into the optimizer's grad_scale, and the rank-ordered
 all-gather used for the ClusterMemory update.  The kernels themselves are GPU-only; this covers the N>1 logic."""
+import atexit
 import datetime
 import os
-import socket
 
 import torch
 import torch.distributed as dist
@@ -14,11 +14,14 @@ from rg_hip.parallel import GradReducer, all_gather_rows, world_size
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """rendezvous token of one test: the path of a fresh file for gloo's FileStore (no TCP port to collide on or to find in
+    TIME_WAIT; the name is kept from the first version, which probed for a free port)"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="rg_gloo_")
+    os.close(fd)
+    os.unlink(path)                       # the store creates it
+    atexit.register(lambda: os.path.exists(path) and os.unlink(path))
+    return path
 
 
 class _FakeOptimizer(object):
@@ -28,9 +31,8 @@ class _FakeOptimizer(object):
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=90))
     try:
         torch.manual_seed(0)                                  # identical replicas
         net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 11))
@@ -129,9 +131,8 @@ def test_arena_views_alias_parameters():
 
 # ---- replicas start identical: rank 0's parameters + buffers are broadcast when the reducer becomes active --------
 def _bcast_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=90))
     try:
         torch.manual_seed(100 + rank)                         # DIFFERENT replicas per rank, as a user script may build them
         net = torch.nn.Sequential(torch.nn.Linear(9, 6), torch.nn.BatchNorm1d(6), torch.nn.Linear(6, 2))
@@ -171,9 +172,8 @@ def test_broadcast_makes_replicas_identical_world2():
 
 
 def _outside_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=90))
     try:
         net = torch.nn.Linear(4, 4)
         arena = Arena(list(net.parameters()))
@@ -216,9 +216,8 @@ def _cpu_cm_update(inputs, targets, features, momentum, hard=False, normalize_ep
 
 
 def _cm_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=90))
     try:
         from rg_hip import ops
         import clustercontrast.models.cm as CMM
