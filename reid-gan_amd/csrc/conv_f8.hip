@@ -685,6 +685,12 @@ static int pad16(int v) { return (v + 15) / 16 * 16; }
         }                                                                                                                  \
     } while (0)
 
+// RG_F8_BM=64|128 pins the tile height of the forward / data-gradient GEMMs (A/B measurements); anything else is ignored
+static int f8_bm_override() {
+    static const int v = getenv("RG_F8_BM") ? atoi(getenv("RG_F8_BM")) : 0;
+    return (v == 64 || v == 128) ? v : 0;
+}
+
 // RG_F8_NB=2 selects the register-staged two-buffer loop (the first version; kept for A/B measurements), default the 4-deep DMA ring
 static int f8_ring() {
     static const int nb = getenv("RG_F8_NB") ? atoi(getenv("RG_F8_NB")) : 4;
@@ -766,7 +772,7 @@ extern "C" int rg_conv2d_f8_fwd(const void* xq, const void* wq, const float* sx,
     p.Cq = Cp / 16;
     p.Kc = KH * KW * p.Cq;
     p.d_cq = make_fastdiv(p.Cq);
-    static const int bm_env = getenv("RG_F8_BM") ? atoi(getenv("RG_F8_BM")) : 0;
+    static const int bm_env = f8_bm_override();
     const int bm = bm_env ? bm_env : (K <= 64 ? 64 : 128), fa = 0, fb = fmt_x;
     p.m_tiles = rg::cdiv(K, bm);
     p.n_tiles = rg::cdiv(p.Ng, BN);
@@ -798,7 +804,7 @@ extern "C" int rg_conv2d_f8_dgrad(const void* dyq, const void* wq_t, const float
     p.M = C;
     p.Cq = Kp / 16;
     p.d_cq = make_fastdiv(p.Cq);
-    static const int bm_env = getenv("RG_F8_BM") ? atoi(getenv("RG_F8_BM")) : 0;
+    static const int bm_env = f8_bm_override();
     const int bm = bm_env ? bm_env : (C <= 64 ? 64 : 128), fa = 0, fb = fmt_dy;
     p.m_tiles = rg::cdiv(C, bm);
     int nt_max = 0;
