@@ -379,10 +379,10 @@ WORKLOADS = {w.key: w for w in (FDGANStep, CCStep, Joint4a, Joint4b, DPTNStep)}
 
 # ---------------------------------------------------------------------------------------------------------------------
 def pmc_traffic(key, launches_per_step):
-    """HBM bytes per conv launch from the committed PMC passes (profiles/r02_pmc_traffic.json; produced on the GPU box by
+    """HBM bytes per conv launch from the committed PMC passes (profiles/r03_pmc_traffic.json, else the round-2 file; produced on the GPU box by
     tools/prof_summary.py + tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     script).  PMC counters cannot be read from inside the process, so the figure is not live; None if absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:
@@ -418,22 +418,6 @@ def measure(w, args, dev, rank, world, use_dist, headline):
             torch.cuda.synchronize()
             log("warm-up step %d done" % i)
     run = w.step
-    graphed = False
-    if args.graph == "on" or (args.graph == "auto" and not use_dist):
-        # the whole step as ONE hipGraph launch (rg_hip/graph.py): captured after the warm-up steps, two replays before the
-        # timed region.  Multi-GPU runs stay eager (RCCL collectives inside a captured step are not validated on this stack).
-        from rg_hip.graph import CapturedStep
-        try:
-            cs = CapturedStep(w.step, warmup=0)
-            cs()
-            cs()
-            torch.cuda.synchronize()
-            run, graphed = cs, True
-        except Exception as e:                                  # fall back to eager launches and say so in the JSON line
-            if args.graph == "on":
-                raise
-            log("config %s: step capture failed (%s: %s); eager launches" % (w.key, type(e).__name__, str(e)[:200]))
-            torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -498,7 +482,7 @@ def measure(w, args, dev, rank, world, use_dist, headline):
     ms_step = 1e3 * elapsed / steps
     return {"value": round(world * w.crops * steps / elapsed, 2), "ms_per_step": round(ms_step, 3), "steps": steps,
             "warmup": warmup, "host_enqueue_ms_per_step": round(1e3 * t_host / steps, 3),
-            "launch": "hipGraph replay of the captured step" if graphed else "eager (one hipLaunchKernel per kernel from Python)",
+            "launch": "eager (one hipLaunchKernel per kernel, issued through the C ABI)",
             "losses": {k: round(float(v), 5) for k, v in losses.items()}, "roofline": roof,
             "step_tflops_algorithmic": round(w.gflop_per_crop * w.crops / 1e3 / (ms_step * 1e-3), 2)}
 
@@ -515,15 +499,25 @@ def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the ranks as a fresh child process tree (this
     process has made no GPU call: importing torch and parsing arguments initialise nothing) and relay its output."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + \
+          [a for a in sys.argv[1:] if a != "--dry-run"]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "ranks": args.gpus, "cmd": cmd,
+                          "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")},
+                          "configs_measured": [args.config] + ([] if args.no_others or args.config != "2" else OTHERS_DIST)}),
+              file=_real_stdout)
+        _real_stdout.flush()
+        return 0
     log("launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
     return subprocess.call(cmd, env=env)
 
 
 _real_stdout = sys.stdout
+OTHERS_SINGLE = ["3", "4a", "4b", "5"]
+OTHERS_DIST = ["4a", "4b", "5"]
 
 
 def main():
@@ -536,10 +530,9 @@ def main():
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each configuration under other_configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="measure only --config")
-    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
-                    help="replay the step as one captured hipGraph (rg_hip/graph.py).  Off by default: measured on ROCm 7.2 the "
-                         "replay of these 1 000+ node multi-stream graphs costs the host as much as the eager launches "
-                         "(profiles/r02_graph_vs_eager.txt)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="with --gpus N outside torch.distributed.run: print the child command that would start the ranks (one "
+                         "JSON line) and exit without touching a GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -575,10 +568,11 @@ def main():
 
     others = None
     if not args.no_others and args.config == "2":
-        # the other BASELINE configurations, measured in the same process behind the headline (single GPU: all of them;
-        # multi-GPU: the joint trainer of BASELINE config 4, which is what the north star's DDP sentence names)
+        # the other BASELINE configurations, measured in the same process behind the headline.  Multi-GPU: the DDP
+        # configurations of BASELINE.json — 4 (the joint trainer: 4a as committed in trainers_b.py:617-814, 4b with FDGANModel
+        # in the GAN role) and 5 (dual_gan DPTNModel, fp8) — so that their scaling curves come out of the same runs
         others = {}
-        keys = ["3", "4a", "4b", "5"] if world == 1 else ["4b"]
+        keys = OTHERS_SINGLE if world == 1 else OTHERS_DIST
         del w
         torch.cuda.empty_cache()
         for k in keys:

@@ -37,7 +37,8 @@ def _first(out):
 
 
 class _ReducerCache(object):
-    """one GradReducer per optimizer object (created lazily, no-op without torch.distributed)."""
+    """one GradReducer per optimizer object (created at the top of the first step — the trainers receive the optimizer per call,
+    not at construction — so rank 0's broadcast precedes the first forward; no-op without torch.distributed)."""
 
     def __init__(self):
         self._r = {}
@@ -96,6 +97,7 @@ class ClusterContrastTrainer(object):
 
     def step(self, inputs, labels, optimizer):
         """One training step (reference loop body :229-244); returns the detached device loss."""
+        self._reducers.get(optimizer, self.encoder)       # replicas are synchronised (rank-0 broadcast) BEFORE the first forward
         f_out = _first(self._forward(inputs))
         loss = RF.weighted_mean(self.memory(f_out, labels))
         optimizer.zero_grad()
@@ -155,6 +157,7 @@ class ClusterContrastWithGANTrainer(object):
             if joint:
                 loss = self.joint_step(reid_inputs, labels, indexes, optimizer, conf_weight)
             else:
+                self._reducers.get(optimizer, self.encoder)
                 out = self._forward(reid_inputs)
                 f_out = _first(out)
                 f_gan = out[1] if isinstance(out, (tuple, list)) else None
@@ -192,6 +195,7 @@ class ClusterContrastWithGANTrainer(object):
         feature -> generator loss (D frozen) + confidence-weighted cluster-contrast loss -> D step -> one backward
         through G and the encoder -> both optimizers step."""
         gan = self.gan
+        self._reducers.get(optimizer, self.encoder)       # rank-0 broadcast before the first forward, not after its backward
         out = self._forward(reid_inputs)
         f_out = _first(out)
         # train-mode encoders return (bn_x, normalize(feature map)) (CC/clustercontrast/models/resnet.py:107); the

@@ -132,6 +132,18 @@ class DPTNModel(BaseModel):
             self._red_D = GradReducer(self.optimizer_D, modules=[self.net_D])
             _wrap_step(self.optimizer_G, self._red_G)
             _wrap_step(self.optimizer_D, self._red_D)
+            if self._f8_states:
+                # delayed fp8 scaling: the maxima collected during a step become current at the step boundary that ALWAYS runs —
+                # the generator's optimizer step, last in the reference's order (DPTN_model.py:216-225) — so a caller that drives
+                # backward_D / backward_G / optimizer_X.step() itself (the joint trainers do) rolls the scales too
+                inner_G = self.optimizer_G.step
+
+                def step_and_roll(*a, **kw):
+                    out = inner_G(*a, **kw)
+                    for st in self._f8_states:
+                        st.roll()
+                    return out
+                self.optimizer_G.step = step_and_roll
         else:
             self.net_G.eval()
 
@@ -240,6 +252,4 @@ class DPTNModel(BaseModel):
 
         self.optimizer_G.zero_grad()
         self.backward_G()
-        self.optimizer_G.step()
-        for st in self._f8_states:          # delayed fp8 scaling: the maxima collected during this step become current
-            st.roll()
+        self.optimizer_G.step()             # (fp8: also rolls the delayed scales, see __init__)

@@ -63,6 +63,15 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+def proto_hash(protos):
+    """sha1 over the canonical prototype list; must match csrc/gen_pymod.py:proto_hash (the generated module embeds it)"""
+    import hashlib
+    h = hashlib.sha1()
+    for name, (ret, args) in protos.items():
+        h.update(("%s|%s|%s\n" % (name, ret, ",".join(t for t, _ in args))).encode())
+    return h.hexdigest()
+
+
 def build(verbose=False):
     """Compile every HIP source for gfx950 into reid-gan_amd/lib/libreidgan_hip.so (in-tree)."""
     cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]
@@ -103,9 +112,11 @@ class _Lib(object):
         return self
 
     def _load_native(self, dll):
-        """the generated CPython binding (csrc/gen_pymod.py): same symbols, ~10 x less call overhead than ctypes.  Optional —
-        without it (or with RG_NATIVE_BIND=0) every call goes through ctypes; either way it is this library that runs."""
-        if os.environ.get("RG_NATIVE_BIND", "1") == "0":
+        """the generated CPython binding (csrc/gen_pymod.py): same symbols, direct argument conversion.  Opt-in (RG_NATIVE_BIND=1):
+        at step level round 2 measured it no faster than ctypes (profiles/r02_host_cost_*.txt); the launch programs replayed in C
+        (rg_hip/program.py) are what removes the per-call cost.  Either way it is this library that runs.  A module generated
+        from a different header (bind() matches names only) is refused: its PROTO_HASH must equal the hash of the header parsed here."""
+        if os.environ.get("RG_NATIVE_BIND", "0") != "1":
             return None
         import glob
         import importlib.machinery
@@ -118,6 +129,9 @@ class _Lib(object):
             spec = importlib.util.spec_from_file_location("_rg_native", cands[0], loader=loader)
             mod = importlib.util.module_from_spec(spec)
             loader.exec_module(mod)
+            want = proto_hash(self.protos)
+            if getattr(mod, "PROTO_HASH", None) != want:
+                raise ImportError("stale module: generated from other prototypes (%s != %s)" % (getattr(mod, "PROTO_HASH", None), want))
             mod.bind({name: ctypes.cast(getattr(dll, name), ctypes.c_void_p).value for name in self.protos})
         except Exception as e:                                   # stale build (header changed): say so, keep working
             import warnings

@@ -17,6 +17,7 @@ from torch.optim import Optimizer
 
 from . import ops
 
+import struct
 import weakref
 
 _ALIGN = 64          # elements; keeps every view 256-byte aligned (float4 kernels, RCCL)
@@ -159,6 +160,7 @@ class _FlatOptimizer(Optimizer):
         a = self._arena
         state = state_dict.get("state", {})
         super(_FlatOptimizer, self).load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        self._reset_state()                  # parameters absent from the loaded state start from zero, as in torch.optim
         for k, entry in state.items():
             i = int(k)
             if not 0 <= i < len(a.params):
@@ -177,7 +179,7 @@ class Adam(_FlatOptimizer):
         self._v = torch.zeros_like(self._arena.flat)
         self._steps = [0] * len(self._arena.params)
         # device-side clocks {step, beta1^step, beta2^step}, one per beta pair: the bias corrections of the fused kernel are
-        # read from device memory, so a captured hipGraph of the step replays correctly (rg_hip.graph)
+        # read from device memory (no per-step value in the kernel arguments: the launch record of a step is replayable)
         self._clocks = {}
         OPTIMIZERS.add(self)
 
@@ -186,10 +188,15 @@ class Adam(_FlatOptimizer):
         parameter that joined late): the by-value kernel then serves that range"""
         c = self._clocks.get((b1, b2))
         if c is None:
-            if step != 0:
-                return None
-            st = torch.tensor([0.0, 1.0, 1.0, 0.0], dtype=torch.float64).to(self._arena.flat.device)
-            c = self._clocks[(b1, b2)] = [st, 0, -1]          # [device state, host mirror of its step, epoch of last advance]
+            # seeded at the CURRENT step count (0 for a fresh optimizer, the resumed count after load_state_dict), in float64
+            # like the clock kernel's own products, so a resumed optimizer stays on the device-clock kernel
+            f1, f2 = struct.unpack("ff", struct.pack("ff", b1, b2))     # the kernel receives the betas as C floats
+            p1 = p2 = 1.0
+            for _ in range(step):                                       # the clock kernel's own sequence of double products
+                p1 *= f1
+                p2 *= f2
+            st = torch.tensor([float(step), p1, p2, 0.0], dtype=torch.float64).to(self._arena.flat.device)
+            c = self._clocks[(b1, b2)] = [st, step, -1]       # [device state, host mirror of its step, epoch of last advance]
         return c if c[1] == step or (c[1] == step + 1 and c[2] == self._arena.epoch) else None
 
     def _uniform_state(self, segs):
@@ -204,9 +211,14 @@ class Adam(_FlatOptimizer):
         return {"step": torch.tensor(float(self._steps[i])), "exp_avg": self._m[o:o + n].view(p.shape).clone(),
                 "exp_avg_sq": self._v[o:o + n].view(p.shape).clone()}
 
+    def _reset_state(self):
+        self._m.zero_()
+        self._v.zero_()
+        self._steps = [0] * len(self._arena.params)
+        self._clocks = {}                    # re-seeded from the resumed step counts at the next step()
+
     def _import_param_state(self, i, o, p, entry):
         n = p.numel()
-        self._clocks = {}                    # resumed step counts: the by-value kernels serve until a fresh optimizer is built
         self._steps[i] = int(entry["step"])
         self._m[o:o + n].copy_(entry["exp_avg"].reshape(-1))
         self._v[o:o + n].copy_(entry["exp_avg_sq"].reshape(-1))
@@ -262,6 +274,10 @@ class SGD(_FlatOptimizer):
             return None
         n = p.numel()
         return {"momentum_buffer": self._buf[o:o + n].view(p.shape).clone()}
+
+    def _reset_state(self):
+        self._buf.zero_()
+        self._started = [False] * len(self._arena.params)
 
     def _import_param_state(self, i, o, p, entry):
         buf = entry.get("momentum_buffer")

@@ -148,25 +148,32 @@ def test_dual_gan_registry():
         DM.find_model_using_name("nope")
 
 
-def test_generated_cpython_binding_and_ctypes_fallback():
-    """lib/_rg_native*.so (generated from the header by csrc/gen_pymod.py) serves every entry point with the ctypes binding's
-    conventions — values for queries, RuntimeError + rg_last_error() text for a non-zero status, TypeError for a wrong
-    argument count; RG_NATIVE_BIND=0 runs the same calls through ctypes."""
+def test_generated_cpython_binding_is_opt_in_and_hash_checked():
+    """ctypes is the default binding.  lib/_rg_native*.so (generated from the header by csrc/gen_pymod.py, RG_NATIVE_BIND=1) serves
+    every entry point with the ctypes binding's conventions — values for queries, RuntimeError + rg_last_error() text for a
+    non-zero status, TypeError for a wrong argument count — and carries the hash of the prototypes it was generated from: a
+    module whose hash differs from the parsed header is refused (bind() matches symbols by name only)."""
     import subprocess
     import sys
     lib = L.lib
     lib.load()
-    assert lib._native is not None, "the generated binding was not built (make -C reid-gan_amd/csrc)"
-    assert all(hasattr(lib._native, n) for n in lib.protos)
-    assert lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32) > 0
+    if os.environ.get("RG_NATIVE_BIND", "0") != "1":
+        assert lib._native is None
+    want = [lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128), lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32)]
     with pytest.raises(RuntimeError, match="rg_fill failed"):
         lib.rg_fill(None, 4, 1.0, None)
-    with pytest.raises(TypeError):
-        lib.rg_fill(None, 4)
-    code = ("import sys; sys.path.insert(0, %r); from rg_hip.lib import lib; lib.load(); assert lib._native is None; "
-            "print(lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128), lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32))"
-            % L.PKG_ROOT)
-    env = dict(os.environ, RG_NATIVE_BIND="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, universal_newlines=True, check=True).stdout.split()
-    assert [int(v) for v in out] == [lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128),
-                                     lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32)]
+    code = ("import sys, warnings; sys.path.insert(0, %r); import rg_hip.lib as L\n"
+            "%s"
+            "lib = L.lib; lib.load(); print(int(lib._native is not None))\n"
+            "print(lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128), lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32))\n"
+            "try:\n    lib.rg_fill(None, 4, 1.0, None)\nexcept RuntimeError as e:\n    print(int('rg_fill failed' in str(e)))\n"
+            "try:\n    lib.rg_fill(None, 4)\nexcept TypeError:\n    print(1)\n")
+
+    def run(pre):
+        env = dict(os.environ, RG_NATIVE_BIND="1", PYTHONWARNINGS="ignore")
+        out = subprocess.run([sys.executable, "-c", code % (L.PKG_ROOT, pre)], env=env, stdout=subprocess.PIPE,
+                             universal_newlines=True, check=True).stdout.split()
+        return [int(v) for v in out]
+    assert run("") == [1] + want + [1, 1]                                            # the generated binding, same answers
+    # a module generated from other prototypes: refused, calls go through ctypes (same answers)
+    assert run("L.proto_hash = lambda protos: 'not-the-hash'\n") == [0] + want + [1, 1]

@@ -285,6 +285,14 @@ def test_optimizer_state_dict_roundtrip(dev):
         n_(x.to(dev)).pow(2).sum().backward()
         o.step()
     assert torch.equal(net.weight, net2.weight)          # the resumed optimizer continues bit-identically
+    assert opt2._clocks and all(c[1] == 3 for c in opt2._clocks.values())     # ... on the device-clock kernel, seeded at step 2
+    # a parameter absent from the loaded state starts from zero moments and step 0 (torch.optim semantics), whatever it held
+    sd_part = {"state": {0: sd["state"][0]}, "param_groups": sd["param_groups"]}
+    opt2.load_state_dict(sd_part)
+    a = opt2._arena
+    o1, n1 = a.offsets[1], a.params[1].numel()
+    assert opt2._steps == [2, 0] and not opt2._m[o1:o1 + n1].any() and not opt2._v[o1:o1 + n1].any()
+    assert torch.equal(opt2._m[a.offsets[0]:a.offsets[0] + a.params[0].numel()].view(5, 6), sd["state"][0]["exp_avg"].to(dev))
 
 
 def test_cascade_evaluator_second_stage(dev):

@@ -10,16 +10,10 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = (("conv_f8", ("conv_f8", "f8_quantize", "f8_splitk", "f8_amax", "f8_roll")),
-            ("conv", ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_splitk_finish", "splitk_reduce", "weights_to_krsc")),
-            ("norm", ("bn_",)), ("optim", ("adam", "sgd")), ("pool", ("maxpool", "global_avgpool", "gem_")))
-
-
-def fam(k):
-    for f, pre in FAMILIES:
-        if k.startswith(pre):
-            return f
-    return "other"
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_families import family_of as fam      # kernel -> family TABLE (round 2 matched name prefixes and booked
+                                                  # conv3x3_halo / bn_fold_wgrad / *_k1 / smallc under "other")
 
 
 def main():
