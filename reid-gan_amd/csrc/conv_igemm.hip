@@ -37,9 +37,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 16;
+#ifndef RG_MATH
+#define RG_MATH 3       // 3: split-bf16 arithmetic (three bf16 pieces per fp32 operand, six MFMA products); 1: fp32 MFMA (below)
+#endif
 #ifndef RG_WAVES
+#if RG_MATH == 3
+#define RG_WAVES 3      // the split fragments (3 x 4 registers per 32 x 16 operand block) need the 168-register budget
+#else
 #define RG_WAVES 4      // waves per SIMD the fwd / dgrad kernels are compiled for (register budget 512 / RG_WAVES; 4 = 128
                         // registers: 2-5 spilled dwords outside the k-loop, +0.8 % on the step over 3)
+#endif
 #endif
 constexpr int LPAD = 4;
 constexpr int NT = 256;
@@ -134,13 +141,92 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called behind the last k-step(s): the kernels use it to write
-// the NEXT tile's staged registers into the other LDS buffer, a quarter at a time, so those ds_writes (and the vmcnt
-// wait in front of them) issue in the shadow of the 64-cycle MFMAs instead of after them.
+// ---- matrix arithmetic of one 16-deep k-tile -------------------------------------------------------------------------------
+// RG_MATH 3 (default): fp32 operands are split EXACTLY into three bf16 pieces each (x = hi + mid + lo with hi = bf16(x),
+// mid = bf16(x - hi), lo = x - hi - mid, each rounded to nearest even: the residuals are exact fp32 subtractions and the last one
+// has at most 8 significant bits, so it is a bf16 number; rounding rather than truncating keeps the residuals' signs independent
+// of the operand's, so the dropped terms below do not add up to a bias — a truncating split underestimates every product by
+// ~2^-24, measured as -4.7e-8 sum|a b| on same-sign data) and the product is evaluated as the six partial products whose weight
+// is >= 2^-16 of the leading one
+//     a*b ~ a_hi b_hi + (a_hi b_mid + a_mid b_hi) + (a_mid b_mid + a_hi b_lo + a_lo b_hi)
+// on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in fp32, accumulation in fp32).  The three dropped products
+// (mid*lo, lo*mid, lo*lo) are <= 2^-23 |a b| together: one fp32 rounding per product, i.e. the error model of the fp32 FMA chain
+// the fp32 MFMA evaluates — measured against fp64 in tests/test_ops_gpu.py — at 6/16 of its matrix-pipe time (the bf16 MFMA
+// issues 16x the FLOPs per cycle).  The split runs on the VALU after the fragment's ds_read_b32s (LDS tiles stay fp32, k-major,
+// shared with RG_MATH 1), 4.5 VALU ops per element; small terms are accumulated first.
+// RG_MATH 1: v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fma chain), the round-1/2 arithmetic.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int int4r __attribute__((ext_vector_type(4)));
+
+struct Split3 {
+    int4r hi, mid, lo;      // 8 bf16 each: element j of the MFMA fragment = k index 8 * (lane >> 5) + j
+};
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float float2r __attribute__((ext_vector_type(2)));
+// two elements at a time: v_cvt_pk_bf16_f32 (round to nearest even) gives the packed pieces directly
+__device__ __forceinline__ void split3_pair(float x0, float x1, int& hi, int& mid, int& lo) {
+    const float2r x = {x0, x1};
+    hi = __builtin_bit_cast(int, __builtin_convertvector(x, bf16x2));
+    const float2r r = {x0 - __builtin_bit_cast(float, (unsigned)hi << 16), x1 - __builtin_bit_cast(float, (unsigned)hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(int, __builtin_convertvector(r, bf16x2));
+    const float2r l = {r[0] - __builtin_bit_cast(float, (unsigned)mid << 16), r[1] - __builtin_bit_cast(float, (unsigned)mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(int, __builtin_convertvector(l, bf16x2));
+}
+
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int h, m, l;
+        split3_pair(x[2 * d], x[2 * d + 1], h, m, l);
+        s.hi[d] = h; s.mid[d] = m; s.lo[d] = l;
+    }
+    return s;
+}
+
+__device__ __forceinline__ floatx16 mfma_bf16(const int4r& a, const int4r& b, const floatx16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc += A(32 x 16) * B(16 x 32) in split arithmetic, small terms first
+__device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, floatx16& acc) {
+    acc = mfma_bf16(a.lo, b.hi, acc);
+    acc = mfma_bf16(a.hi, b.lo, acc);
+    acc = mfma_bf16(a.mid, b.mid, acc);
+    acc = mfma_bf16(a.mid, b.hi, acc);
+    acc = mfma_bf16(a.hi, b.mid, acc);
+    acc = mfma_bf16(a.hi, b.hi, acc);
+}
+
+// One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called behind the last matrix instructions: the kernels use it to write
+// the NEXT tile's staged registers into the other LDS buffer, so those ds_writes (and the vmcnt wait in front of them) issue in
+// the shadow of the MFMAs instead of after them.
 template <typename T, typename Hook>
 __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float (*Bs)[T::LDB],
                                          floatx16 (&acc)[T::TM][T::TN], int wm, int wn, int lane, Hook hook) {
     const int l32 = lane & 31, kh = lane >> 5;
+#if RG_MATH == 3
+    static_assert(BK == 16, "one bf16 MFMA k-step per LDS tile");
+    Split3 a[T::TM];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = As[8 * kh + j][wm * T::WTM + i * 32 + l32];
+        a[i] = split3(x);
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = Bs[8 * kh + q][wn * T::WTN + j * 32 + l32];
+        const Split3 b = split3(x);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) mma_split3(a[i], b, acc[i][j]);
+    }
+    hook(0); hook(1); hook(2); hook(3);
+#else
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
         const int k = 2 * ks + kh;
@@ -149,35 +235,16 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
         for (int i = 0; i < T::TM; ++i) a[i] = As[k][wm * T::WTM + i * 32 + l32];
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) b[j] = Bs[k][wn * T::WTN + j * 32 + l32];
-#ifdef RG_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int j = 0; j < T::TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-#ifdef RG_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef RG_EARLY_STORE
-        if (ks >= BK / 4) hook(ks - BK / 4);                  // stores of the next tile spread over the last four k-steps
-#else
         // stores of the next tile behind the LAST k-step: the global loads issued at the top of the tile get 7/8 of its
-        // matrix work as cover before their first use.  Measured at 3 waves/SIMD: last two k-steps -0.7 ms per FD-GAN
-        // step over the last four; at 4 waves/SIMD: last k-step only +1.5 % on the conv family over the last two
-#if defined(RG_STORE_2)
-        if (ks == BK / 2 - 2) { hook(0); hook(1); }
-        if (ks == BK / 2 - 1) { hook(2); hook(3); }
-#elif defined(RG_STORE_3)
-        if (ks == BK / 2 - 3) { hook(0); }
-        if (ks == BK / 2 - 2) { hook(1); }
-        if (ks == BK / 2 - 1) { hook(2); hook(3); }
-#else
+        // matrix work as cover before their first use
         if (ks == BK / 2 - 1) { hook(0); hook(1); hook(2); hook(3); }
-#endif
-#endif
     }
+#endif
 }
 
 // true when element e of a CNT-element staging array belongs to quarter q (q < 0: every quarter)
@@ -685,6 +752,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
             const int r = (t * 11) >> 5;                       // t / 3 for t < 9
             const int toff = (r - 1) * Wh + (t - 3 * r - 1);
             const float* hsb = Hs[hb];
+#if RG_MATH == 3
+            {
+                Split3 a[T::TM];
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = As[ab][8 * kh + q][wm * T::WTM + i * 32 + l32];
+                    a[i] = split3(x);
+                }
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = hsb[(8 * kh + q) * HP + pos[j] + toff];
+                    const Split3 b = split3(x);
+#pragma unroll
+                    for (int i = 0; i < T::TM; ++i) mma_split3(a[i], b, acc[i][j]);
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
                 const int k = 2 * ks + kh;
@@ -699,6 +787,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
                     for (int j = 0; j < T::TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+#endif
             if (!last) store_a(ab ^ 1);
             if (t == 8 && more_cb) store_h(hb ^ 1);
             __syncthreads();

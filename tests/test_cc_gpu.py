@@ -148,21 +148,38 @@ def test_cc_trainer_step_resnet50(dev):
 
 def test_cc_trainer_three_steps(dev):
     """Three consecutive steps (forward, CM backward + ordered bank update, per-tensor-group Adam with weight
-    decay) on ResNet-18, whose gradients are well conditioned in fp32: per-step loss within 1e-3."""
+    decay) on ResNet-18, whose gradients are well conditioned in fp32: per-step loss within 1e-3 of the fp32 oracle.
+    The bank rows written after step >= 1 are features of weights that went through Adam steps — a g / (|g| + eps) update
+    that amplifies rounding differences of the gradients — so two fp32 implementations are not compared with each other
+    there: both are judged against an fp64 run of the oracle, and the HIP path must stay as close to it as the oracle's own
+    fp32 CPU run does (factor 2 for the run-to-run spread; measured: the two distances are within 20 % of each other)."""
+    import copy
     from oracle import ref_torch as O
     from clustercontrast.trainers import ClusterContrastTrainer
     from rg_hip import optim as roptim
     o, r, om, rm, g, K = _trainer_pair(O, dev, 18)
+    o64, om64 = copy.deepcopy(o).double(), copy.deepcopy(om)
+    om64.features = om.features.double()
     oopt, ropt = _per_tensor_adam(o, torch.optim.Adam), _per_tensor_adam(r, roptim.Adam)
+    oopt64 = _per_tensor_adam(o64, torch.optim.Adam)
     trainer = ClusterContrastTrainer(r, rm)
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).norm() / b.norm()).item()
     for it in range(3):
         x = O.synth_images(16, 128, 64, seed=10 + it)
         labels = torch.randint(0, K, (4,), generator=g).repeat_interleave(4)
         lo = O.o_cc_step(o, om, oopt, x, labels)
+        lo64 = O.o_cc_step(o64, om64, oopt64, x.double(), labels)
         lr = trainer.step(x.to(dev), labels.to(dev), ropt).item()
         assert abs(lr - lo) <= 1e-3 * abs(lo), "step %d loss %r vs %r" % (it, lr, lo)
-        # the rows written into the bank are features of weights that went through `it` Adam steps
-        _check_l2(rm.features, om.features, 1e-3 if it == 0 else 3e-3, "bank after step %d" % it)
+        assert abs(lr - lo64) <= 1e-3 * abs(lo64), "step %d loss %r vs fp64 %r" % (it, lr, lo64)
+        d_hip, d_cpu = rel(rm.features, om64.features), rel(om.features, om64.features)
+        print("bank after step %d: HIP vs fp64 %.3e, fp32 CPU oracle vs fp64 %.3e" % (it, d_hip, d_cpu))
+        if it == 0:
+            _check_l2(rm.features, om.features, 1e-3, "bank after step 0")
+        assert d_hip <= max(1e-3, 2.0 * d_cpu), "bank after step %d: HIP %.3e from the fp64 trajectory, the fp32 oracle %.3e" % (it, d_hip, d_cpu)
 
 
 def test_cm_gan(dev):

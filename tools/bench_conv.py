@@ -38,8 +38,18 @@ def uniq(shapes):
 
 
 def timeit(fn, reps=5):
+    """ms per call.  Default: the library's per-launch HIP events (rg::ProfScope, on the launch stream) — the kernels of the small
+    layers take 10-30 us, less than one Python call, so host-side timing of back-to-back calls measures the host (RG_BENCH_HOST=1)."""
     fn()
     torch.cuda.synchronize()
+    if os.environ.get("RG_BENCH_HOST") != "1":
+        ops.profile_reset()
+        ops.profile_enable(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        ops.profile_enable(False)
+        return sum(f["ms"] for f in ops.profile_collect().values()) / reps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -64,7 +74,10 @@ def main():
                   ("de1(convT as conv 3->64)", 1, 3, 256, 128, 64, 4, 2, 1)]
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     print("%-28s %3s %22s %9s | %8s %8s %8s (TFLOP/s)   ms f/d/w" % ("layer", "cnt", "N,C,H,W->K k s p", "GFLOP", "fwd", "dgrad", "wgrad"))
+    only = os.environ.get("RG_BENCH_ONLY")
     for name, cnt, C, H, W, K, k, s, p in shapes:
+        if only and name not in only.split(","):
+            continue
         x = torch.randn(N, C, H, W, device=dev)
         w = torch.randn(K, C, k, k, device=dev) * 0.05
         y = ops.conv2d_fwd(x, w, s, p)
