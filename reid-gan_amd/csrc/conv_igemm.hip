@@ -199,6 +199,64 @@ __device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, flo
     acc = mfma_bf16(a.hi, b.hi, acc);
 }
 
+#ifndef RG_PINSCHED
+#define RG_PINSCHED 1
+#endif
+#if RG_PINSCHED
+#define RG_PIN() __builtin_amdgcn_sched_barrier(0)      // keep the (MFMA, split pair) groups in source order
+#else
+#define RG_PIN()
+#endif
+
+#if RG_MATH == 3
+// One 16-deep k-step of a (TM x 32) x (TN x 32) wave tile from fp32 operands in LDS: ra(i, q) / rb(j, q) read element q (k index
+// 8 * (lane >> 5) + q) of this lane's row of A block i / column of B block j.
+// Software-pipelined by hand: the matrix pipe and the VALU do not overlap across the waves of a SIMD here (the co-resident
+// workgroups run in phase: PMC showed VALU-busy + MFMA-busy = kernel time), so each wave hides its own split work behind its own
+// MFMAs: block order (0,0), (1,0), .., (0,1), .. needs one new fragment per block; while the six MFMAs of a block issue, the
+// fragment of the NEXT block is split, one element pair (9 VALU instructions) behind each of the first four.
+template <int TM, int TN, typename RA, typename RB>
+__device__ __forceinline__ void mma_kstep(RA ra, RB rb, floatx16 (&acc)[TM][TN]) {
+    float xa[TM][8], xb[TN][8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xa[i][q] = ra(i, q);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xb[j][q] = rb(j, q);
+    Split3 a[TM], b[TN];
+    a[0] = split3(xa[0]);
+    b[0] = split3(xb[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // fragment the next block needs first: a[i + 1] in the first column, b[j + 1] at the end of a column
+            const bool na = (j == 0 && i + 1 < TM), nb = (i + 1 == TM && j + 1 < TN);
+            const int ia = i + 1 < TM ? i + 1 : 0, jb = j + 1 < TN ? j + 1 : 0;
+            auto pair = [&](int d) {
+                int h, m, l;
+                if (na) {
+                    split3_pair(xa[ia][2 * d], xa[ia][2 * d + 1], h, m, l);
+                    a[ia].hi[d] = h; a[ia].mid[d] = m; a[ia].lo[d] = l;
+                } else if (nb) {
+                    split3_pair(xb[jb][2 * d], xb[jb][2 * d + 1], h, m, l);
+                    b[jb].hi[d] = h; b[jb].mid[d] = m; b[jb].lo[d] = l;
+                }
+            };
+            floatx16& c = acc[i][j];
+            c = mfma_bf16(a[i].lo, b[j].hi, c);  pair(0);  RG_PIN();
+            c = mfma_bf16(a[i].hi, b[j].lo, c);  pair(1);  RG_PIN();
+            c = mfma_bf16(a[i].mid, b[j].mid, c);  pair(2);  RG_PIN();
+            c = mfma_bf16(a[i].mid, b[j].hi, c);  pair(3);  RG_PIN();
+            c = mfma_bf16(a[i].hi, b[j].mid, c);
+            c = mfma_bf16(a[i].hi, b[j].hi, c);
+        }
+}
+#endif
+
 // One 16-deep k-tile of MFMAs.  `hook(q)`, q = 0..3, is called behind the last matrix instructions: the kernels use it to write
 // the NEXT tile's staged registers into the other LDS buffer, so those ds_writes (and the vmcnt wait in front of them) issue in
 // the shadow of the MFMAs instead of after them.
@@ -208,23 +266,8 @@ __device__ __forceinline__ void mma_tile(const float (*As)[T::LDA], const float 
     const int l32 = lane & 31, kh = lane >> 5;
 #if RG_MATH == 3
     static_assert(BK == 16, "one bf16 MFMA k-step per LDS tile");
-    Split3 a[T::TM];
-#pragma unroll
-    for (int i = 0; i < T::TM; ++i) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = As[8 * kh + j][wm * T::WTM + i * 32 + l32];
-        a[i] = split3(x);
-    }
-#pragma unroll
-    for (int j = 0; j < T::TN; ++j) {
-        float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = Bs[8 * kh + q][wn * T::WTN + j * 32 + l32];
-        const Split3 b = split3(x);
-#pragma unroll
-        for (int i = 0; i < T::TM; ++i) mma_split3(a[i], b, acc[i][j]);
-    }
+    mma_kstep<T::TM, T::TN>([&](int i, int q) { return As[8 * kh + q][wm * T::WTM + i * 32 + l32]; },
+                            [&](int j, int q) { return Bs[8 * kh + q][wn * T::WTN + j * 32 + l32]; }, acc);
     hook(0); hook(1); hook(2); hook(3);
 #else
 #pragma unroll
@@ -753,25 +796,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void co
             const int toff = (r - 1) * Wh + (t - 3 * r - 1);
             const float* hsb = Hs[hb];
 #if RG_MATH == 3
-            {
-                Split3 a[T::TM];
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i) {
-                    float x[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = As[ab][8 * kh + q][wm * T::WTM + i * 32 + l32];
-                    a[i] = split3(x);
-                }
-#pragma unroll
-                for (int j = 0; j < T::TN; ++j) {
-                    float x[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = hsb[(8 * kh + q) * HP + pos[j] + toff];
-                    const Split3 b = split3(x);
-#pragma unroll
-                    for (int i = 0; i < T::TM; ++i) mma_split3(a[i], b, acc[i][j]);
-                }
-            }
+            mma_kstep<T::TM, T::TN>([&](int i, int q) { return As[ab][8 * kh + q][wm * T::WTM + i * 32 + l32]; },
+                                    [&](int j, int q) { return hsb[(8 * kh + q) * HP + pos[j] + toff]; }, acc);
 #else
 #pragma unroll
             for (int ks = 0; ks < BK / 2; ++ks) {
