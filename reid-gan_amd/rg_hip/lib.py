@@ -112,11 +112,13 @@ class _Lib(object):
         return self
 
     def _load_native(self, dll):
-        """the generated CPython binding (csrc/gen_pymod.py): same symbols, direct argument conversion.  Opt-in (RG_NATIVE_BIND=1):
-        at step level round 2 measured it no faster than ctypes (profiles/r02_host_cost_*.txt); the launch programs replayed in C
-        (rg_hip/program.py) are what removes the per-call cost.  Either way it is this library that runs.  A module generated
-        from a different header (bind() matches names only) is refused: its PROTO_HASH must equal the hash of the header parsed here."""
-        if os.environ.get("RG_NATIVE_BIND", "0") != "1":
+        """the generated CPython binding (csrc/gen_pymod.py): same symbols, direct argument conversion, GIL released around every
+        launching entry point.  Default on (RG_NATIVE_BIND=0 selects ctypes): measured at step level on the same box with the
+        4-crop batches where step time = host cost (profiles/r03_host_cost.txt): config 5 15.7 vs 17.0 ms, config 2 19.6 vs
+        20.9 ms per step (round 2's version held the GIL across the calls and was SLOWER than ctypes).  Either way it is this
+        library that runs.  A module generated from a different header (bind() matches names only) is refused: its PROTO_HASH
+        must equal the hash of the header parsed here."""
+        if os.environ.get("RG_NATIVE_BIND", "1") == "0":
             return None
         import glob
         import importlib.machinery

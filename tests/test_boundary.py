@@ -149,7 +149,7 @@ def test_dual_gan_registry():
 
 
 def test_generated_cpython_binding_is_opt_in_and_hash_checked():
-    """ctypes is the default binding.  lib/_rg_native*.so (generated from the header by csrc/gen_pymod.py, RG_NATIVE_BIND=1) serves
+    """lib/_rg_native*.so (generated from the header by csrc/gen_pymod.py; default binding, RG_NATIVE_BIND=0 selects ctypes) serves
     every entry point with the ctypes binding's conventions — values for queries, RuntimeError + rg_last_error() text for a
     non-zero status, TypeError for a wrong argument count — and carries the hash of the prototypes it was generated from: a
     module whose hash differs from the parsed header is refused (bind() matches symbols by name only)."""
@@ -157,8 +157,8 @@ def test_generated_cpython_binding_is_opt_in_and_hash_checked():
     import sys
     lib = L.lib
     lib.load()
-    if os.environ.get("RG_NATIVE_BIND", "0") != "1":
-        assert lib._native is None
+    if os.environ.get("RG_NATIVE_BIND", "1") != "0":
+        assert lib._native is not None, "the generated binding was not built (make -C reid-gan_amd/csrc)"
     want = [lib.rg_version(), lib.rg_bn_train_fused_ok(64, 1024, 128), lib.rg_conv2d_wgrad_workspace(32, 64, 64, 3, 3, 64, 32)]
     with pytest.raises(RuntimeError, match="rg_fill failed"):
         lib.rg_fill(None, 4, 1.0, None)
@@ -175,5 +175,9 @@ def test_generated_cpython_binding_is_opt_in_and_hash_checked():
                              universal_newlines=True, check=True).stdout.split()
         return [int(v) for v in out]
     assert run("") == [1] + want + [1, 1]                                            # the generated binding, same answers
+    env0 = dict(os.environ, RG_NATIVE_BIND="0", PYTHONWARNINGS="ignore")
+    out0 = subprocess.run([sys.executable, "-c", code % (L.PKG_ROOT, "")], env=env0, stdout=subprocess.PIPE, universal_newlines=True,
+                          check=True).stdout.split()
+    assert [int(v) for v in out0] == [0] + want + [1, 1]                             # ctypes, same answers
     # a module generated from other prototypes: refused, calls go through ctypes (same answers)
     assert run("L.proto_hash = lambda protos: 'not-the-hash'\n") == [0] + want + [1, 1]
