@@ -42,8 +42,11 @@ def _check_anchored(got, ref32, ref64, what, floor=1e-3, factor=4.0):
     return e_hip, e_cpu
 
 
-def _check_grads_anchored(rg_mod, o32, o64, what, floor=2e-3, factor=3.0, tensor_floor=2e-2):
-    """Noise-dominated gradients (see _check_anchored): per tensor the errors of two fp32 implementations are
+def _check_grads_anchored(rg_mod, o32, o64, what, floor=2e-3, factor=3.0, tensor_floor=5e-2):
+    """(`tensor_floor`: one activation that takes the other LeakyReLU branch — the two implementations differ by a few 1e-7 in front
+    of the kink — moves single entries of a small affine / bias gradient by up to a few per cent of that tensor's largest entry;
+    measured 0.7-2.4e-2 across the rounding variants of the conv kernels, while the kink-free twins of these tests hold 2e-5.)
+    Noise-dominated gradients (see _check_anchored): per tensor the errors of two fp32 implementations are
     independent draws, so compare (a) the global relative L2 error over ALL parameters and (b) every tensor
     against the WORST tensor of the reference's own fp32 path."""
     g32, g64 = dict(o32.named_parameters()), dict(o64.named_parameters())
@@ -72,8 +75,10 @@ def _check_grads_anchored(rg_mod, o32, o64, what, floor=2e-3, factor=3.0, tensor
     return l2_h, l2_c
 
 
-def _check_grads(rg_mod, o_mod, tol, what, skip=(), tol_tensor=1e-2, tol_max=0.5):
-    """relative L2 error over all parameters <= tol, per tensor <= tol_tensor, max norm <= tol_max."""
+def _check_grads(rg_mod, o_mod, tol, what, skip=(), tol_tensor=1e-2, tol_max=1e-1):
+    """relative L2 error over all parameters <= tol, per tensor <= tol_tensor, max norm <= tol_max.  The max-norm bound is a
+    statement about ReLU / LeakyReLU branch flips, not about kernels (measured <= 5e-2; the kink-free tests in test_exact_gpu.py
+    and *_without_kinks hold 2e-5 / 1e-4 in the max norm)."""
     og = dict(o_mod.named_parameters())
     gmax = max(p.grad.abs().max().item() for p in og.values() if p.grad is not None)
     num = den = 0.0
@@ -100,7 +105,7 @@ def _check_grads(rg_mod, o_mod, tol, what, skip=(), tol_tensor=1e-2, tol_max=0.5
     return g
 
 
-def _check_l2(got, ref, tol, what, tol_max=0.5):
+def _check_l2(got, ref, tol, what, tol_max=1e-1):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     l2 = (got - ref).norm().item() / max(ref.norm().item(), 1e-300)
     assert l2 <= tol, "%s: rel L2 err %.3e" % (what, l2)
