@@ -97,6 +97,7 @@ struct ConvP {
     int N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q;
     int M, Ng, Kg;
     int a_vec4;
+    int wshift;          // wgrad, VEC instantiation: the im2col operand is a SHIFTED copy of x (stride 1): float4 loads at the tap's offset
     int m_tiles, n_tiles;
     FastDiv d_rs, d_kw, d_pq, d_q;
     // split-K (fwd / dgrad: partial tiles to `partial`; wgrad: to y)
@@ -1454,10 +1455,20 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
         const int m = m0 + vrow + 64 * i;
         avoff[i] = (vrow + 64 * i < BM && m < p.M) ? (unsigned)m * (unsigned)PQ * 4u : OOB;
     }
+    int vrr[BVN], vss[BVN];               // p.wshift: tap offset (r - PH, s - PW) of the row's column n = (c, r, s)
 #pragma unroll
     for (int i = 0; i < BVN; ++i) {
-        const int c = n0 + vrow + 64 * i;
-        bvoff[i] = (vrow + 64 * i < BN && c < p.Ng) ? (unsigned)c * (unsigned)HW * 4u : OOB;
+        const int n = n0 + vrow + 64 * i;
+        int c = n;
+        vrr[i] = vss[i] = 0;
+        if (p.wshift) {
+            c = fdiv(n, p.d_rs);
+            const int rs = n - c * RS;
+            const int r = fdiv(rs, p.d_kw);
+            vrr[i] = r - p.PH;
+            vss[i] = rs - r * p.KW - p.PW;
+        }
+        bvoff[i] = (vrow + 64 * i < BN && n < p.Ng) ? (unsigned)c * (unsigned)HW * 4u : OOB;
     }
 
     auto load_tile = [&](int kt) {
@@ -1471,6 +1482,27 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const ConvP p) {
             for (int i = 0; i < AVN; ++i) {
                 const float4 t = bload4(rdy, ((ab | avoff[i]) & OOB) ? OOB : ab + avoff[i]);
                 ra[4 * i + 0] = t.x; ra[4 * i + 1] = t.y; ra[4 * i + 2] = t.z; ra[4 * i + 3] = t.w;
+            }
+            if (VEC && p.wshift) {
+                // stride-1 filter tap (r, s): the four output pixels (pp, q0 .. q0 + 3) read x at (pp + r - PH, q0 + s - PW ..), four
+                // CONSECUTIVE floats (Q % 4 == 0 keeps a quad inside one row).  One column may fall off either end of the row
+                // (|s - PW| <= 1): the load is moved one element inwards and the vector shifted, so every address stays inside
+                // the row (dword-aligned dwordx4 buffer loads are legal; nothing relies on partial out-of-range returns)
+                const int pp = fdiv(pq, p.d_q);
+                const int q0 = pq - pp * p.Q;
+#pragma unroll
+                for (int i = 0; i < BVN; ++i) {
+                    const int hh = pp + vrr[i], wb = q0 + vss[i];
+                    const bool ok = gvalid && bvoff[i] != OOB && (unsigned)hh < (unsigned)p.H;
+                    const bool neg = wb < 0, over = wb + 3 >= p.W;
+                    const int e = img * p.C * HW + hh * p.W + wb + (neg ? 1 : 0) - (over ? 1 : 0);
+                    const float4 t = bload4(rx, ok ? (unsigned)e * 4u + bvoff[i] : OOB);
+                    rb[4 * i + 0] = neg ? 0.f : (over ? t.y : t.x);
+                    rb[4 * i + 1] = neg ? t.x : (over ? t.z : t.y);
+                    rb[4 * i + 2] = neg ? t.y : (over ? t.w : t.z);
+                    rb[4 * i + 3] = neg ? t.z : (over ? 0.f : t.w);
+                }
+                return;
             }
             if (VEC) {
                 const unsigned bb = gvalid ? (unsigned)(img * p.C * HW + pq) * 4u : OOB;
@@ -1631,6 +1663,7 @@ static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int
     p.d_pq = make_fastdiv(P * Q);
     p.d_q = make_fastdiv(Q);
     p.a_vec4 = 0;
+    p.wshift = 0;
     p.ktiles_per_split = 1 << 30;
     p.splits = 1;
     p.partial = nullptr;
@@ -2186,7 +2219,7 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
     WgradPlan pl;
     // the reduction (N*P*Q) is long, so parallelism comes from split-K: always take the largest tile that fits
     // (a 64x64 tile issues 2x the LDS reads and 4x the loader instructions per MFMA of the 128x128 one)
-    pl.tile = (M <= 32) ? 3 : ((M <= 64 || Ng <= 64) ? 2 : 0);
+    pl.tile = (M <= 32) ? 3 : ((M <= 64 || Ng <= 64) ? 2 : 0);     // (64 x 128 for M = 64 measured 8-10 % slower than 64 x 64 here)
     pl.m_tiles = rg::cdiv(M, kTileBM[pl.tile]);
     pl.n_tiles = rg::cdiv(Ng, kTileBN[pl.tile]);
     const int64_t nk = rg::cdiv64(Kg, BK);
@@ -2277,7 +2310,12 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         rg::ProfScope prof(rg::FAM_CONV_WGRAD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
         const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
         const bool veca = al && ((P * Q) % 4 == 0);
-        const bool vec = veca && KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0;
+        bool vec = veca && KH == 1 && KW == 1 && SH == 1 && SW == 1 && PH == 0 && PW == 0;
+        static const int shift_env = getenv("RG_WGRAD_SHIFT") ? atoi(getenv("RG_WGRAD_SHIFT")) : 1;
+        if (!vec && !rsc && shift_env && veca && SH == 1 && SW == 1 && PW <= 1 && KW <= PW + 2 && Q % 4 == 0 && W >= 4 && KW * KH > 1) {
+            vec = true;                  // im2col operand = shifted float4 loads of x (conv_wgrad_kernel, p.wshift)
+            p.wshift = 1;
+        }
 #define RG_WGRAD_LAUNCH(BM_, BN_, WM_, WN_)                                                                        \
     if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, true, true>), grid, dim3(NT), 0, stream, p); \
     else if (veca) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NT), 0, stream, p); \
