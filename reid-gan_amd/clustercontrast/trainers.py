@@ -15,6 +15,7 @@ from __future__ import print_function, absolute_import
 import time
 
 import torch
+from rg_hip.tape import backward as _backward
 import torch.nn as nn
 
 from rg_hip import functional as RF
@@ -101,7 +102,7 @@ class ClusterContrastTrainer(object):
         f_out = _first(self._forward(inputs))
         loss = RF.weighted_mean(self.memory(f_out, labels))
         optimizer.zero_grad()
-        loss.backward()
+        _backward(loss)
         self._reducers.get(optimizer, self.encoder).reduce()
         optimizer.step()
         return loss.detach()
@@ -164,7 +165,7 @@ class ClusterContrastWithGANTrainer(object):
                 loss_ori = self.memory(f_out, labels, gan_inputs=None if f_gan is None else f_gan.detach())
                 loss = RF.weighted_mean(loss_ori)
                 optimizer.zero_grad()
-                loss.backward()
+                _backward(loss)
                 self._reducers.get(optimizer, self.encoder).reduce()
                 optimizer.step()
                 loss = loss.detach()
@@ -216,7 +217,7 @@ class ClusterContrastWithGANTrainer(object):
 
         gan.optimizer_G.zero_grad()
         optimizer.zero_grad()
-        loss.backward()
+        _backward(loss)
         self._reducers.get(optimizer, self.encoder).reduce()
         gan.optimizer_G.step()
         optimizer.step()

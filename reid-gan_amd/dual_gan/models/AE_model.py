@@ -18,6 +18,7 @@ from __future__ import absolute_import
 import itertools
 
 import torch
+from rg_hip.tape import backward as _backward
 
 from rg_hip import functional as RF
 from rg_hip import nn as rnn
@@ -198,7 +199,7 @@ class AEModel(BaseModel):
         base_function._unfreeze(self.net_D)
         self.loss_dis_img_gen = self.backward_D_basic(self.net_D, self.source_image, self.fake_image)
         self.loss_D = self.loss_dis_img_gen
-        self.loss_D.backward()
+        _backward(self.loss_D)
         self.loss_D = self.loss_D.detach()
 
     # ---- generator losses (AE_model.py:316-376) ------------------------------------------------------------
@@ -235,7 +236,7 @@ class AEModel(BaseModel):
         self.loss_G = self._loss_G_mean()
         if loss_nl is not None:
             self.loss_G = _weighted([(self.loss_G, 1.0), (loss_nl, 1.0)])
-        self.loss_G.backward()
+        _backward(self.loss_G)
         self.loss_G = self.loss_G.detach()
 
     def get_loss_G(self, group_size=None, cf_temp=0.2, need_cm=True, cluster_features=None):

@@ -28,6 +28,7 @@ import itertools
 import os
 
 import torch
+from rg_hip.tape import backward as _backward
 
 from rg_hip import functional as RF
 from rg_hip import optim as roptim
@@ -199,7 +200,7 @@ class DPTNModel(BaseModel):
         base_function._unfreeze(self.net_D)
         self.loss_dis_img_gen_t = self.backward_D_basic(self.net_D, self.target_image, self.fake_image_t)
         D_loss = self.loss_dis_img_gen_t
-        D_loss.backward()
+        _backward(D_loss)
         self.loss_dis_img_gen_t = D_loss.detach()
 
     # ---- generator update (DPTN_model.py:184-214) ----------------------------------------------------------------
@@ -237,7 +238,7 @@ class DPTNModel(BaseModel):
             terms += [(self.loss_style_gen_t, r), (self.loss_content_gen_t, r), (self.loss_style_gen_s, 1 - r),
                       (self.loss_content_gen_s, 1 - r)]
         G_loss = _weighted(terms)
-        G_loss.backward(retain_graph=retain_graph)
+        _backward(G_loss, retain_graph=retain_graph)
         for n in ('app_gen_t', 'ad_gen_t', 'style_gen_t', 'content_gen_t', 'app_gen_s', 'style_gen_s', 'content_gen_s'):
             setattr(self, 'loss_' + n, getattr(self, 'loss_' + n).detach())
 

@@ -26,6 +26,7 @@ import random
 from collections import OrderedDict
 
 import torch
+from rg_hip.tape import backward as _backward
 
 from fdgan.losses import GANLoss
 from fdgan.networks import (CustomPoseGenerator, NLayerDiscriminator, get_norm_layer, get_scheduler, init_weights,
@@ -222,7 +223,7 @@ class FDGANModel(object):
             loss_D_real = self.criterionGAN_D(pred_real, True)
             loss_D_fake = self.criterionGAN_D(pred_fake, False)
         loss_D = _weighted([(loss_D_real, 0.5), (loss_D_fake, 0.5)])
-        loss_D.backward()
+        _backward(loss_D)
         self.loss_Dp = loss_D.detach()
 
     def backward_Di(self):
@@ -234,7 +235,7 @@ class FDGANModel(object):
             loss_D_real = self.criterionGAN_D(pred_real, True)
             loss_D_fake = self.criterionGAN_D(pred_fake, False)
         loss_D = _weighted([(loss_D_real, 0.5), (loss_D_fake, 0.5)])
-        loss_D.backward()
+        _backward(loss_D)
         self.loss_Di = loss_D.detach()
 
     def build_loss_G(self):
@@ -278,7 +279,7 @@ class FDGANModel(object):
         return loss_G
 
     def backward_G(self):
-        self.build_loss_G().backward()
+        _backward(self.build_loss_G())
         del self.id_score
         self.fake = self.fake.detach()
 

@@ -28,6 +28,11 @@ WEIGHT_EPOCH = [0]      # bumped by rg_hip.optim after every step (its kernels b
 BN_LAYERS = weakref.WeakSet()      # rg_hip.graph advances their host-side `num_batches_tracked` bookkeeping per replay
 
 
+def _geom_gflop(geom, dy):
+    """algorithmic GFLOP of one conv pass with geometry (N, C, H, W, K, KH, KW, ...) and output gradient dy"""
+    return 2e-9 * dy.numel() * geom[1] * geom[5] * geom[6]
+
+
 def _bias_grad(tape, bias, dy):
     """sum of dy over N and the pixels.  When dy is the tensor an InstanceNorm backward just produced, that kernel already
     summed it per (n, c): one tiny launch over [N][C] instead of another pass over the activation."""
@@ -142,7 +147,8 @@ class Conv2d(RGModule, _KrscCache):
             dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
             if want_w:
                 gout = tape.grad_out(self.weight)
-                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(xq_t, dyq_t, geom, out=gout), xq_t, dyq_t, gout))
+                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(xq_t, dyq_t, geom, out=gout), xq_t, dyq_t, gout,
+                                                           worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:
@@ -242,7 +248,8 @@ class ConvTranspose2d(RGModule, _KrscCache):
             if want_w:
                 # filter gradient with the roles swapped: the "input" is dy (e5m2), the "output gradient" is x (e4m3)
                 gout = tape.grad_out(self.weight)
-                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(dyq_t, xq_t, geom, out=gout), xq_t, dyq_t, gout))
+                tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(dyq_t, xq_t, geom, out=gout), xq_t, dyq_t, gout,
+                                                           worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:
@@ -859,7 +866,7 @@ class SNConv2d(RGModule):
                 gout = tape.grad_out(self.weight_orig)
                 tape.add_grad(self.weight_orig, ops.side_call(
                     lambda: ops.spectral_norm_bwd(lowp.conv_wgrad(x, dyq_t, geom), w_sn, u, v, sigma, out=gout),
-                    x, dyq_t, w_sn, u, v, sigma, gout))
+                    x, dyq_t, w_sn, u, v, sigma, gout, worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
             if tape.wants(self.bias):
                 _bias_grad(tape, self.bias, dy)
             if not need_dx:

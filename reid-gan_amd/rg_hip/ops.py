@@ -16,9 +16,16 @@ from .lib import lib
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 
 
+_DEV = [None]
+
+
 def _stream():
-    """raw hipStream_t of torch's current stream on the current device (fast path: no Stream object is built)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    """raw hipStream_t of torch's current stream on this process's device (fast path: no Stream object is built; one process
+    drives one GPU, so the device index is looked up once)"""
+    d = _DEV[0]
+    if d is None:
+        d = _DEV[0] = torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(d)
 
 
 def _chk(t, name="tensor", dtype=torch.float32):
@@ -216,11 +223,21 @@ def side_join():
         sess.used = False
 
 
-def side_call(fn, *operands):
+# Moving a launch to the side stream costs the host ~60 us (event record / wait, stream switch: profiles/r03_host_cost.txt shows
+# 3.0 ms per step for the 48 side launches of the DPTN step, whose kernels take 5-20 us each): only work that runs long enough for
+# the overlap to buy something goes there.  Estimated from the algorithmic FLOPs at the rates the kernel families reach.
+_SIDE_MIN_US = float(os.environ.get("RG_SIDE_MIN_US", "25"))
+
+
+def side_worth(gflop, fp8=False):
+    return gflop / (0.30 if fp8 else 0.08) >= _SIDE_MIN_US
+
+
+def side_call(fn, *operands, worth=True):
     """run `fn()` — a leaf of the backward program (weight-gradient work) — on the session's side stream, ordered behind
     everything the main stream has launched so far; `operands` (and fn's result) stay referenced until the join.  Inline when
-    no session is open or the side stream is switched off."""
-    if _SIDE["on"]:
+    no session is open, the side stream is switched off, or the work is too short to be worth the hand-off (`worth`)."""
+    if _SIDE["on"] and worth:
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
             ev = torch.cuda.Event()
@@ -237,7 +254,7 @@ def side_call(fn, *operands):
 def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
     """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
     behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
-    if side and _SIDE["on"]:
+    if side and _SIDE["on"] and side_worth(2e-9 * dy.numel() * w_shape[1] * w_shape[2] * w_shape[3]):
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
             x, dy = _chk(x, "x"), _chk(dy, "dy")

@@ -107,6 +107,21 @@ class _NetFn(torch.autograd.Function):
         return (None, None) + tuple(d if n else None for d, n in zip(dxs, need)) + tuple(grads)
 
 
+_AUTOGRAD_MT = __import__("os").environ.get("RG_AUTOGRAD_MT") == "1"      # A/B switch: leave the engine's worker thread on
+
+
+def backward(loss, **kw):
+    """loss.backward() with the network backward programs run on the CALLING thread: the autograd engine otherwise hands every
+    node to its per-device worker thread, and the hand-off (plus the GIL ping-pong between the two threads while one of them
+    enqueues kernels) costs ~1 ms per step on the small-kernel steps (tools/debug/host_cost.py: DPTN step 15.7 -> 14.8 ms).
+    Streams behave as before: the engine restores each node's forward stream either way."""
+    if _AUTOGRAD_MT:
+        loss.backward(**kw)
+        return
+    with torch.autograd.set_multithreading_enabled(False):
+        loss.backward(**kw)
+
+
 def _param_list(net):
     """list(net.parameters()), built once per network: walking the module tree on every call costs milliseconds per
     step on the small-kernel networks, whose steps are host-bound.  The tree of a built network does not change; call

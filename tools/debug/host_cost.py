@@ -42,6 +42,10 @@ def main():
     t_all = time.perf_counter() - t0
     print("config %s at %d crops: %.2f ms/step, host enqueue %.2f ms/step" % (key, crops, 1e3 * t_all / n, 1e3 * t_host / n))
     from rg_hip import lib as L
+    if os.environ.get("RG_PROFILE_BACKWARD") == "1":
+        # the autograd engine runs backward() on its own device thread, which cProfile does not see: single-threaded mode runs the
+        # network backward programs in the calling thread, so their Python cost shows up in the table below
+        torch.autograd.set_multithreading_enabled(False)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(n):
