@@ -157,6 +157,7 @@ class Workload(object):
                    "split exactly into 3 bf16 pieces, 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 "
                    "accumulation (dropped terms <= 2^-23 per product: fp32-grade, tests at the round-2 2e-5 bounds)")
     mfma_products = 6                 # bf16 matrix products issued per algorithmic fp32 product
+    launch_note = "eager (one hipLaunchKernel per kernel, issued through the C ABI)"
     describe = ""
 
     def build(self, dev, rank):
@@ -287,6 +288,8 @@ class Joint4a(Workload):
     key = "4a"
     crops = 32
     gflop_per_crop = 32.0
+    launch_note = ("the GAN networks' forward / backward programs replayed as single-stream hipGraphs captured per network "
+                   "(rg_hip/netgraph.py; RG_NET_GRAPHS=0 = eager); everything else eager, one hipLaunchKernel per kernel through the C ABI")
     describe = ("joint ReID + GAN step as committed (ClusterContrastWithGANTrainer.joint_step, trainers_b.py:617-774): "
                 "cluster-contrast encoder + dual_gan AEModel('Pose', layers 3) at 128x64 + spectral-norm D, 32 crops per GPU")
 
@@ -344,6 +347,8 @@ class DPTNStep(Workload):
     key = "5"
     crops = 64
     gflop_per_crop = 20.6
+    launch_note = ("the GAN networks' forward / backward programs replayed as single-stream hipGraphs captured per network "
+                   "(rg_hip/netgraph.py; RG_NET_GRAPHS=0 = eager); everything else eager, one hipLaunchKernel per kernel through the C ABI")
     dtype = "fp8"
     peak = F8_MFMA_PEAK_TFLOPS
     mfma_products = 1
@@ -494,7 +499,7 @@ def measure(w, args, dev, rank, world, use_dist, headline):
     ms_step = 1e3 * elapsed / steps
     return {"value": round(world * w.crops * steps / elapsed, 2), "ms_per_step": round(ms_step, 3), "steps": steps,
             "warmup": warmup, "host_enqueue_ms_per_step": round(1e3 * t_host / steps, 3),
-            "launch": "eager (one hipLaunchKernel per kernel, issued through the C ABI)",
+            "launch": w.launch_note,
             "losses": {k: round(float(v), 5) for k, v in losses.items()}, "roofline": roof,
             "step_tflops_algorithmic": round(w.gflop_per_crop * w.crops / 1e3 / (ms_step * 1e-3), 2)}
 

@@ -98,6 +98,13 @@ class AEModel(BaseModel):
                 self.model_names.append('Db')
                 self.net_Db = networks.define_D(opt, ndf=32, img_f=128, layers=opt.dis_layers, use_spect=opt.use_spect_d)
 
+        # the small-kernel GAN networks run their forward / backward programs as captured single-stream hipGraphs (rg_hip.netgraph):
+        # their steps are otherwise bound by the host's launch rate
+        for _n in ('net_G', 'net_Gb', 'net_D', 'net_Db'):
+            _m = getattr(self, _n, None)
+            _m = getattr(_m, "module", _m)             # through the DataParallel shim
+            if _m is not None:
+                _m.__dict__["_rg_graph"] = True
         if getattr(self.opt, 'verbose', False):
             print('---------- Networks initialized -------------')
 

@@ -114,6 +114,13 @@ class DPTNModel(BaseModel):
             if self.gan_train:
                 self._f8_states.append(lowp.set_conv_dtype(self.net_D, 'fp8', policy=policy, keep_fp32=keep_D))
 
+        # the small-kernel GAN networks run their forward / backward programs as captured single-stream hipGraphs (rg_hip.netgraph):
+        # their steps are otherwise bound by the host's launch rate
+        for _n in ('net_G', 'net_D'):
+            _m = getattr(self, _n, None)
+            _m = getattr(_m, "module", _m)             # through the DataParallel shim
+            if _m is not None:
+                _m.__dict__["_rg_graph"] = True
         if getattr(self.opt, 'verbose', False):
             print('---------- Networks initialized -------------')
         if self.gan_train:

@@ -268,6 +268,10 @@ class DPTNGenerator(RGModule):
         self._is_train = bool(is_train)
         return super(DPTNGenerator, self).forward(source, source_B, target_B)
 
+    def _rg_key(self):
+        """state outside the tensor arguments that selects the program (rg_hip.netgraph keys its records on it)"""
+        return getattr(self, "_is_train", True)
+
     def _enc(self):
         return ([self.block0] + [getattr(self, 'encoder' + str(i)) for i in range(self.layers - 1)] +
                 [getattr(self, 'mblock' + str(i)) for i in range(self.num_blocks)])

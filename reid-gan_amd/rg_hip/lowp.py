@@ -193,7 +193,7 @@ class F8Layer(object):
     def weights(self, w, key=None):
         """(wq [K][RS][Cp], wq_t [C][RS][Kp]) of the filter tensor, re-quantised (always with a fresh amax: filters are
         small) when `key` changes; key=None: every call (spectral-normed filters change every forward)."""
-        if key is None or key != self._wkey:
+        if key is None or key != self._wkey or ops.CAPTURING[0]:
             # filters change by one optimizer step between uses: the previous step's maximum scales them (delayed policy);
             # 'jit' measures first
             self.sw.prepare(w)

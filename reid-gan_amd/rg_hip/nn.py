@@ -67,7 +67,7 @@ class _KrscCache(object):
             return None
         arena = getattr(w, "_rg_arena", None)          # the fused optimizers bump their own arena's epoch
         key = (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
-        if getattr(self, "_wk_key", None) != key:
+        if getattr(self, "_wk_key", None) != key or ops.CAPTURING[0]:
             self._wk = ops.weights_to_krsc(w.detach())
             self._wk_key = key
         return self._wk

@@ -17,6 +17,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 
 
 _DEV = [None]
+CAPTURING = [0]      # > 0 while rg_hip.netgraph captures a network program: caches refresh unconditionally (their launches are recorded)
 
 
 def _stream():

@@ -146,6 +146,11 @@ def run(net, *xs):
     need_graph = grad_on and (len(params) > 0 or any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs))
     if not need_graph:
         return net.tf(Tape(param_grad=False, record=False), *xs)
+    if net.__dict__.get("_rg_graph", False):
+        # small-kernel networks: forward / backward programs replayed as two single-stream hipGraphs (rg_hip.netgraph)
+        from . import netgraph
+        if netgraph.ENABLED:
+            return netgraph.call(net, xs, params, lambda: _NetFn.apply(net, len(xs), *xs, *params))
     return _NetFn.apply(net, len(xs), *xs, *params)
 
 
