@@ -420,7 +420,7 @@ def pmc_traffic(key, launches_per_step):
 def measure(w, args, dev, rank, world, use_dist, headline):
     """warm-up, timed region (barrier + synchronize on both sides, MAX over ranks), then the profiled steps on every rank"""
     from rg_hip import ops
-    steps, warmup = (args.steps, args.warmup) if headline else (args.other_steps, 2)
+    steps, warmup = (args.steps, args.warmup) if headline else (args.other_steps, 3)
 
     def barrier():
         torch.cuda.synchronize()
@@ -551,7 +551,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2", choices=sorted(WORKLOADS))
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each configuration under other_configs")
+    ap.add_argument("--other-steps", type=int, default=8, help="timed steps of each configuration under other_configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="measure only --config")
     ap.add_argument("--dry-run", action="store_true",
