@@ -1039,6 +1039,104 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     store_tile_epilogue_any<T>(p, acc, ob, (unsigned)HW * 4u, mrow0, (cl.poff + nt) * WN + wn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 / stride 1 / pad 0 data gradient with LDS-DMA staging.  Both operands are k-major in memory exactly as the LDS tile wants
+// them: the filter tile [16 ko][BM c] is 16 rows of W[K][C], the gradient tile [16 ko][128 pixels] 16 channel rows of dy — so
+// `buffer_load_dwordx4 ... lds` moves them global -> LDS with no staging registers, no ds_write and no VALU (lane l of wave w lands at
+// (w * 64 + l) * 16 bytes of a 4 KiB pass = row pass*R + (w*64 + l) / (ROWS/4), 16-byte column (w*64 + l) % (ROWS/4): lane-linear).
+// Ring of NB = 3 LDS tiles: two k-tiles in flight per workgroup behind the one being multiplied, counted `s_waitcnt vmcnt`, ONE raw
+// s_barrier per k-tile (a __syncthreads would drain the DMAs).  The unpadded k-major rows keep the fragment reads conflict-free
+// (lane = row, consecutive floats).  Same epilogue, same split-K as conv_dgrad_kernel<MODE 2>, whose launches it replaces when the
+// planner picks a 128-pixel tile.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int BM>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) void conv1x1_dma_kernel(const DgradP dp) {
+    using T = Tile<BM, 128, 2, 2>;
+    constexpr int NB = 3;
+    constexpr int ATILE = BK * BM * 4, BTILE = BK * 128 * 4;          // bytes
+    constexpr int APASS = ATILE / 4096, BPASS = BTILE / 4096;         // 4 KiB passes (256 lanes x 16 B) per tile
+    constexpr int LPT = APASS + BPASS;                                // DMA instructions per thread and k-tile
+    static_assert(APASS >= 1 && ATILE % 4096 == 0, "filter tile is a whole number of DMA passes");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NB][ATILE + BTILE];
+    const ConvP& p = dp.c;
+    const DgradClass& cl = dp.cls[0];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int nwg = p.m_tiles * cl.ntiles;
+    if ((int)blockIdx.x >= nwg) return;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
+    const int m0 = mt * BM, n0 = nt * 128;
+    const int split = blockIdx.y;
+    const int PQ = p.P * p.Q;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rdy = make_rsrc(p.x, p.x_bytes);
+
+    // ---- DMA source offsets of this lane (k row 0 of the pass) ----
+    constexpr int ALANES = BM / 4, AROWS = 256 / ALANES;              // lanes per filter row, filter rows per pass
+    const int acol = (tid % ALANES) * 4, arow = tid / ALANES;
+    const unsigned aoff = (m0 + acol < p.M) ? (unsigned)((arow * p.C + m0 + acol) * 4) : OOB;      // W[ko][c]: row stride C
+    const int bcol = (tid & 31) * 4, brow = tid >> 5;                 // 32 lanes per 128-pixel row, 8 rows per pass
+    unsigned boff = OOB;
+    {
+        const int n = n0 + bcol;
+        if (n < cl.Ngc) {
+            const int img = fdiv(n, cl.d_hw);
+            boff = (unsigned)((((int64_t)img * p.K + brow) * PQ + (n - img * PQ)) * 4);
+        }
+    }
+    const unsigned lds_lane0 = (unsigned)__builtin_amdgcn_readfirstlane(wid) * 1024u;
+
+    auto dma_tile = [&](int kt, int buf) {
+        const int kbase = kt * BK;
+        unsigned char* base = lds[buf] + lds_lane0;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int k = kbase + arow + i * AROWS;
+            const unsigned o = (aoff != OOB && k < p.K) ? aoff + (unsigned)((kbase + i * AROWS) * p.C) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(base + i * 4096), 16, (int)o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const int k = kbase + brow + i * 8;
+            const unsigned o = (boff != OOB && k < p.K) ? boff + (unsigned)((kbase + i * 8) * PQ) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(base + ATILE + i * 4096), 16, (int)o, 0, 0, 0);
+        }
+    };
+
+    floatx16 acc[T::TM][T::TN];
+    zero_acc<T>(acc);
+    const int nk = (p.K + BK - 1) / BK;
+    const int kt_begin = split * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    if (kt_end > nk) kt_end = nk;
+    const int nkt = kt_end > kt_begin ? kt_end - kt_begin : 0;
+#pragma unroll
+    for (int sidx = 0; sidx < NB - 1; ++sidx)
+        if (sidx < nkt) dma_tile(kt_begin + sidx, sidx);
+    int buf = 0;
+    for (int it = 0; it < nkt; ++it) {
+        // tile `it` has landed once at most the younger tile's DMAs (issued after it) are outstanding
+        if (it + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's part of tile `it` is in LDS; every wave is done reading tile it-1
+        if (it + NB - 1 < nkt) {
+            int nbuf = buf + NB - 1;
+            if (nbuf >= NB) nbuf -= NB;
+            dma_tile(kt_begin + it + NB - 1, nbuf);          // into the buffer tile it-1 used
+        }
+        const float* As = reinterpret_cast<const float*>(lds[buf]);
+        const float* Bs = reinterpret_cast<const float*>(lds[buf] + ATILE);
+        mma_kstep<T::TM, T::TN>([&](int i, int q) { return As[(8 * kh + q) * BM + wm * T::WTM + i * 32 + l32]; },
+                                [&](int j, int q) { return Bs[(8 * kh + q) * 128 + wn * T::WTN + j * 32 + l32]; }, acc);
+        if (++buf == NB) buf = 0;
+    }
+    store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * 2 + wn);
+}
+
 // Data gradient for layers with <= 4 input channels (the RGB stem, FD/reid/models/resnet.py via torchvision conv1;
 // the generator's 64 -> 3 output ConvTranspose, FD/fdgan/networks.py:133-138).  A 32-row MFMA tile would be > 87 %
 // padding there, so this is a direct VALU kernel: one thread per input pixel of one stride-parity class (uniform
@@ -2172,7 +2270,14 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     p.partial_bytes = (unsigned)need;
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
-    RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
+    static const int dma_env = getenv("RG_CONV_DMA") ? atoi(getenv("RG_CONV_DMA")) : 1;
+    if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {
+        // 1x1 / stride 1: both operands are lane-linear in memory -> LDS-DMA ring (conv1x1_dma_kernel)
+        if (pl.tile == 0) hipLaunchKernelGGL((conv1x1_dma_kernel<128>), grid, dim3(NT), 0, stream, dp);
+        else hipLaunchKernelGGL((conv1x1_dma_kernel<64>), grid, dim3(NT), 0, stream, dp);
+    } else {
+        RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
+    }
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
         hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * ng_max)), dim3(256), 0, stream,
