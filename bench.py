@@ -453,6 +453,13 @@ def measure(w, args, dev, rank, world, use_dist, headline):
     if rank == 0:
         log("config %s: timed %d steps: %.2f ms/step (host enqueue %.2f)" % (w.key, steps, 1e3 * elapsed / steps,
                                                                              1e3 * t_host / steps))
+        if w.capture_steps and os.environ.get("RG_BENCH_DEBUG") == "1":
+            from rg_hip import netgraph as NG
+            for name in ("net_G", "net_D"):
+                net = getattr(getattr(w, "gan", None), name, None)
+                net = getattr(net, "module", net)
+                if net is not None:
+                    log("   %s graphs: %s" % (name, [(c, r, ok) for c, r, ok in NG.stats(net).values()]))
 
     # ---- roofline: per-launch HIP events on the conv implicit-GEMM kernels; EVERY rank runs these steps (collectives) ----
     roof = None
