@@ -139,6 +139,52 @@ class OAEGenerator(nn.Module):
         return self.forward_dec(self.forward_enc(x))
 
 
+class ODECGenerator1(nn.Module):
+    """networks.py:401-444 (`--model_gen DEC`): FeatureAdaptBlock1 -> ResBlocks -> ResBlockDecoders -> Output"""
+
+    def __init__(self, ngf=64, img_f=256, layers=3, norm='instance', output_nc=3, num_blocks=3, feat_nc=2048):
+        super(ODECGenerator1, self).__init__()
+        self.layers, self.num_blocks = layers, num_blocks
+        mult = 4
+        self.feature_block = OFeatureAdaptBlock1(feat_nc, ngf * mult, norm)
+        for i in range(num_blocks):
+            setattr(self, 'mblock%d' % i, OResBlock(ngf * mult, ngf * mult, ngf * mult, norm))
+        for i in range(layers):
+            prev = mult
+            mult = min(2 ** (layers - i - 2), img_f // ngf) if i != layers - 1 else 1
+            setattr(self, 'decoder%d' % i, OResBlockDecoder(ngf * prev, ngf * mult, ngf * mult, norm))
+        self.outconv = OOutput(ngf, output_nc, 3)
+
+    def forward(self, f):
+        f = self.feature_block(f)
+        for i in range(self.num_blocks):
+            f = getattr(self, 'mblock%d' % i)(f)
+        for i in range(self.layers):
+            f = getattr(self, 'decoder%d' % i)(f)
+        return self.outconv(f)
+
+
+class ODECGenerator(nn.Module):
+    """networks.py:356-398: ResBlock(img_f -> 4 ngf) -> ResBlockDecoders -> Output"""
+
+    def __init__(self, ngf=64, img_f=2048, layers=3, norm='instance', output_nc=3):
+        super(ODECGenerator, self).__init__()
+        self.layers = layers
+        mult = 4
+        self.resblock = OResBlock(img_f, ngf * mult, ngf * mult, norm)
+        for i in range(layers):
+            prev = mult
+            mult = min(2 ** (layers - i - 2), img_f // ngf) if i != layers - 1 else 1
+            setattr(self, 'decoder%d' % i, OResBlockDecoder(ngf * prev, ngf * mult, ngf * mult, norm))
+        self.outconv = OOutput(ngf, output_nc, 3)
+
+    def forward(self, f):
+        f = self.resblock(f)
+        for i in range(self.layers):
+            f = getattr(self, 'decoder%d' % i)(f)
+        return self.outconv(f)
+
+
 def o_hard_mix(F_s, reid_f, group_size, lambda_fus):
     """AE_model.py:274-292"""
     fdim = reid_f.shape[1]

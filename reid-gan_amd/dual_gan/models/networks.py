@@ -32,9 +32,16 @@ def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='
     elif opt.model_gen == 'DPTN':
         netG = DPTNGenerator(image_nc, pose_nc, ngf, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc,
                              num_blocks, affine, nhead, num_CABs, num_TTBs)
-    elif opt.model_gen in ('DEC', 'FD', 'PoseAE'):
-        raise NotImplementedError("generator '%s' is not built on the HIP path ('Pose' — the joint training step —, 'AE' and "
-                                  "'DPTN' are)" % opt.model_gen)
+    elif opt.model_gen == 'DEC':
+        netG = DECGenerator1(ngf, img_f, encoder_layer, norm, activation, use_spect, use_coord, output_nc, num_blocks)
+    elif opt.model_gen == 'PoseAE':
+        # the reference's PoseAEGenerator cannot run: its two-argument forward_enc calls itself with one argument
+        # (networks.py:811-813, TypeError on the first forward), so there is no behaviour to reproduce
+        raise NotImplementedError("generator 'PoseAE' fails on its first forward in the reference (networks.py:811-813); "
+                                  "it is not built on the HIP path")
+    elif opt.model_gen == 'FD':
+        raise NotImplementedError("generator 'FD' (FDGenerator under the dual_gan options) is not built on the HIP path; the "
+                                  "FD-GAN generator of the joint step is fdgan.model / 'Pose'")
     else:
         raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
     return init_net(netG, opt.init_type)
@@ -341,6 +348,82 @@ def _dptn_input_grads(d, B, d_source):
                    ops.slice_channels(bot, c_img, c_img + c_pose))
     g_tb = ops.slice_channels(bot, c_img + c_pose, c_img + 2 * c_pose)
     return g_src, g_sb, g_tb
+
+
+class DECGenerator1(RGModule):
+    """Decoder-only generator of `--model_gen DEC` (networks.py:401-444): ReID feature map [B, 2048, h, w] -> FeatureAdaptBlock1
+    (2048 -> 4*ngf) -> `num_blocks` ResBlocks -> `layers` residual up-sampling decoders -> Output; image [B, 3, h*2^layers, w*2^layers].
+    AEModel.synthesize(features) drives it (AE_model.py:209-210)."""
+
+    def __init__(self, ngf=64, img_f=256, layers=3, norm='batch', activation='ReLU', use_spect=True, use_coord=False,
+                 output_nc=3, num_blocks=3):
+        super(DECGenerator1, self).__init__()
+        print("DECGenerator1 init")
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        mult = 4
+        self.feature_block = FeatureAdaptBlock1(2048, ngf * mult, norm_layer, nonlinearity)
+        self.num_blocks = num_blocks
+        for i in range(num_blocks):
+            setattr(self, 'mblock' + str(i), ResBlock(ngf * mult, ngf * mult, norm_layer=norm_layer, nonlinearity=nonlinearity,
+                                                      use_spect=use_spect, use_coord=use_coord))
+        for i in range(self.layers):
+            mult_prev = mult
+            mult = min(2 ** (self.layers - i - 2), img_f // ngf) if i != self.layers - 1 else 1
+            setattr(self, 'decoder' + str(i), ResBlockDecoder(ngf * mult_prev, ngf * mult, ngf * mult, norm_layer, nonlinearity,
+                                                              use_spect, use_coord))
+        self.outconv = Output(ngf, output_nc, 3, None, nonlinearity, use_spect, use_coord)
+
+    def _chain(self):
+        return ([self.feature_block] + [getattr(self, 'mblock' + str(i)) for i in range(self.num_blocks)] +
+                [getattr(self, 'decoder' + str(i)) for i in range(self.layers)] + [self.outconv])
+
+    def tf(self, tape, feature):
+        for m in self._chain():
+            feature = m.tf(tape, feature)
+        return feature
+
+    def tb(self, tape, dy, need_dx=True):
+        mods = self._chain()
+        for i in range(len(mods) - 1, -1, -1):
+            dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
+        return dy
+
+
+class DECGenerator(RGModule):
+    """The earlier decoder-only generator (networks.py:356-398; `define_G` keeps it commented out, networks.py:23): one ResBlock
+    img_f -> 4*ngf straight on the feature map, then the same decoders and Output as DECGenerator1."""
+
+    def __init__(self, ngf=64, img_f=2048, layers=3, norm='batch', activation='ReLU', use_spect=True, use_coord=False,
+                 output_nc=3, num_blocks=3):
+        super(DECGenerator, self).__init__()
+        self.layers = layers
+        norm_layer = get_norm_layer(norm_type=norm)
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        mult = 4
+        self.resblock = ResBlock(img_f, ngf * mult, norm_layer=norm_layer, nonlinearity=nonlinearity, use_spect=use_spect,
+                                 use_coord=use_coord)
+        for i in range(self.layers):
+            mult_prev = mult
+            mult = min(2 ** (self.layers - i - 2), img_f // ngf) if i != self.layers - 1 else 1
+            setattr(self, 'decoder' + str(i), ResBlockDecoder(ngf * mult_prev, ngf * mult, ngf * mult, norm_layer, nonlinearity,
+                                                              use_spect, use_coord))
+        self.outconv = Output(ngf, output_nc, 3, None, nonlinearity, use_spect, use_coord)
+
+    def _chain(self):
+        return [self.resblock] + [getattr(self, 'decoder' + str(i)) for i in range(self.layers)] + [self.outconv]
+
+    def tf(self, tape, inputs):
+        for m in self._chain():
+            inputs = m.tf(tape, inputs)
+        return inputs
+
+    def tb(self, tape, dy, need_dx=True):
+        mods = self._chain()
+        for i in range(len(mods) - 1, -1, -1):
+            dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
+        return dy
 
 
 class PoseGenerator1(RGModule):

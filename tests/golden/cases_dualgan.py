@@ -73,3 +73,24 @@ def dptn_case():
     a = D.synth_dualgan_inputs(2, 64, 32, seed=87)
     b = D.synth_dualgan_inputs(2, 64, 32, seed=88)
     return net, (a['Xs'], a['Ps'], b['Ps'])
+
+
+def decgen1_case():
+    """`--model_gen DEC`: ReID feature map in, image out"""
+    torch.manual_seed(60)
+    net = D.o_init_weights(D.ODECGenerator1(ngf=64, img_f=256, layers=3, norm='instance', output_nc=3, num_blocks=3))
+    _perturb(net, 61)
+    net.train()
+    g = torch.Generator().manual_seed(62)
+    feat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
+    return net, feat
+
+
+def decgen_case():
+    torch.manual_seed(64)
+    net = D.o_init_weights(D.ODECGenerator(ngf=64, img_f=2048, layers=3, norm='instance', output_nc=3))
+    _perturb(net, 65)
+    net.train()
+    g = torch.Generator().manual_seed(66)
+    feat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
+    return net, feat

@@ -114,6 +114,34 @@ def main():
     out["aegen_fwd"], out["aegen_fwd_stats"] = sub(yr)
     out["aegen_enc"], out["aegen_enc_stats"] = sub(rn.forward_enc(x))
 
+    print("DECGenerator1 / DECGenerator")
+    for tag, case, ctor, gsel in (
+            ("decgen1", C.decgen1_case,
+             lambda: ref_net.DECGenerator1(64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3),
+             ["feature_block.model.0.weight", "mblock0.conv1.weight", "mblock2.bypass.bias", "decoder0.model.2.weight",
+              "decoder2.shortcut.0.weight", "outconv.conv1.weight"]),
+            ("decgen", C.decgen_case,
+             lambda: ref_net.DECGenerator(64, 2048, 3, 'instance', 'LeakyReLU', False, False, 3),
+             ["resblock.conv1.weight", "resblock.bypass.weight", "decoder1.model.5.weight", "outconv.conv1.bias"])):
+        on, feat = case()
+        rn = ctor()
+        rn.load_state_dict(on.state_dict())
+        rn.train()
+        feat_r, feat_o = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        yo, yr = on(feat_o), rn(feat_r)
+        check(yo, yr, tag + "_fwd")
+        g = torch.Generator().manual_seed(7)
+        dy = torch.randn(yr.shape, generator=g)
+        yo.backward(dy)
+        yr.backward(dy)
+        check(feat_o.grad, feat_r.grad, tag + "_dfeat", 1e-4)
+        out[tag + "_fwd"], out[tag + "_fwd_stats"] = sub(yr)
+        out[tag + "_dfeat"], out[tag + "_dfeat_stats"] = sub(feat_r.grad)
+        pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+        for k in gsel:
+            check(po[k].grad, pr[k].grad, tag + " grad " + k, 2e-4)
+            out[tag + "_g_" + k], _ = sub(pr[k].grad)
+
     print("DPTNGenerator")
     on, (xs, ps, pt) = C.dptn_case()
     rn = ref_net.DPTNGenerator(3, 18, 64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3, True, 2, 2, 2)

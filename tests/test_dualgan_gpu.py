@@ -2,6 +2,7 @@
 (oracle/ref_dualgan.py, pinned on the reference by tests/golden/reference_dualgan.npz) on identical seeded weights and
 inputs.  Forward 1e-3 max-norm (measured ~1e-5); gradients by the flip-robust L2 metrics of test_modules_gpu.py."""
 import argparse
+import copy
 import os
 
 import numpy as np
@@ -296,6 +297,70 @@ def test_aegenerator_and_gan_step(dev):
     assert abs(errs["G"] - omodel.loss_G.item()) <= 1e-3 * abs(omodel.loss_G.item()), (errs, omodel.loss_G.item())
     _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params")
     _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params")
+
+
+def test_dec_generators(dev):
+    """`--model_gen DEC` (DECGenerator1, networks.py:401-444) and the older DECGenerator (networks.py:356-398): forward, input
+    gradient and parameter gradients against the oracle (== reference, golden fixture), then define_G's 'DEC' branch."""
+    from dual_gan.models import networks as N
+    from tests.golden import cases_dualgan as C
+    from tests.golden.cases import sub
+    for tag, case, ctor in (
+            ("decgen1", C.decgen1_case, lambda: N.DECGenerator1(64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3)),
+            ("decgen", C.decgen_case, lambda: N.DECGenerator(64, 2048, 3, 'instance', 'LeakyReLU', False, False, 3))):
+        on, feat = case()
+        rg = _load(ctor(), on, dev)
+        rg.train()
+        # gradients are judged against an fp64 evaluation of the oracle: on this case torch's own fp32 CPU backward is 1.2e-2
+        # (relative L2) away from fp64 — a LeakyReLU gate decided the other way behind an instance norm — while the HIP path
+        # is 2e-6 away (tools/debug/dec_err.py)
+        on = copy.deepcopy(on).double()
+        fo = feat.double().requires_grad_(True)
+        fd = feat.to(dev).requires_grad_(True)
+        yo, y = on(fo), rg(fd)
+        _check(y, yo, 1e-3, tag + " fwd")
+        ref = GOLD[tag + "_fwd"]
+        got = np.asarray(sub(y.detach().cpu())[0], dtype=np.float64).reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+        g = torch.Generator().manual_seed(7)
+        dy = torch.randn(yo.shape, generator=g)
+        yo.backward(dy.double())
+        y.backward(dy.to(dev))
+        _check_l2(fd.grad, fo.grad, 1e-3, tag + " dfeat")
+        _check_grads(rg, on, 1e-3, tag + " grads", tol_tensor=2e-2)
+    # define_G builds DECGenerator1 for 'DEC' with the reference's argument order (networks.py:21-22)
+    opt = argparse.Namespace(model_gen='DEC', init_type='orthogonal', gpu_ids=[0])
+    net = N.define_G(opt, image_nc=3, pose_nc=18, ngf=64, img_f=256, encoder_layer=3, norm='instance', activation='LeakyReLU',
+                     use_spect=False, use_coord=False, output_nc=3, num_blocks=3)
+    inner = net.module if hasattr(net, "module") else net
+    assert type(inner).__name__ == "DECGenerator1"
+    on, feat = C.decgen1_case()
+    inner.load_state_dict(on.state_dict())
+    _check(net(feat.to(dev)), on(feat), 1e-3, "define_G DEC fwd")
+    for gen in ("PoseAE", "FD"):
+        with pytest.raises(NotImplementedError):
+            N.define_G(argparse.Namespace(model_gen=gen, init_type='orthogonal', gpu_ids=[0]), 3, 18)
+    # AEModel with --model_gen DEC: synthesize(features) (AE_model.py:209-210), then the stand-alone D / G update on it
+    from dual_gan.models.models import create_model
+    from oracle import ref_dualgan as D
+    od, _ = C.resdisc_case()
+    model = create_model(_gan_opt(model="AE", model_gen="DEC"))
+    model.net_G.module.load_state_dict(on.state_dict())
+    model.net_D.module.load_state_dict(od.state_dict())
+    omodel = D.OAEModel(on, od)
+    inp = D.synth_dualgan_inputs(2, 64, 32, seed=34)
+    omodel.set_input(inp)
+    omodel.fake_image = on(feat)
+    omodel.optimize_generated()
+    model.set_input(inp)
+    model.synthesize(feat.to(dev))
+    _check(model.fake_image, omodel.fake_image, 1e-3, "AEModel DEC synthesize")
+    model.optimize_generated()
+    errs = model.get_current_errors()
+    assert abs(errs["D"] - omodel.loss_D.item()) <= 1e-3 * abs(omodel.loss_D.item()), (errs, omodel.loss_D.item())
+    assert abs(errs["G"] - omodel.loss_G.item()) <= 1e-3 * abs(omodel.loss_G.item()), (errs, omodel.loss_G.item())
+    _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params (DEC)")
+    _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params (DEC)")
 
 
 def test_dptn_generator(dev):

@@ -94,6 +94,24 @@ def test_aegenerator():
     _cmp(st, "aegen_enc_stats")
 
 
+def test_dec_generators():
+    for tag, case in (("decgen1", C.decgen1_case), ("decgen", C.decgen_case)):
+        net, feat = case()
+        feat = feat.clone().requires_grad_(True)
+        y = net(feat)
+        s, st = sub(y)
+        _cmp(s, tag + "_fwd")
+        _cmp(st, tag + "_fwd_stats")
+        g = torch.Generator().manual_seed(7)
+        y.backward(torch.randn(y.shape, generator=g))
+        _cmp(sub(feat.grad)[0], tag + "_dfeat", 1e-4)
+        params = dict(net.named_parameters())
+        pre = tag + "_g_"
+        for key in GOLD.files:
+            if key.startswith(pre):
+                _cmp(sub(params[key[len(pre):]].grad)[0], key, 2e-4)
+
+
 def test_dptn_generator():
     net, (xs, ps, pt) = C.dptn_case()
     t, s_ = net(xs, ps, pt)
