@@ -207,6 +207,14 @@ int rg_f8_quantize(const float* in, void* out, float* state, float* scale_out, i
 /* both layouts of in[N][C][L] from ONE pass over the fp32 data: a [N][L][Cp] and b [C][L][Np] (either may be NULL) */
 int rg_f8_quantize_dual(const float* in, void* a, void* b, float* state, float* scale_out, int fmt, int N, int C, int L,
                         rg_stream_t stream);
+/* the output-gradient operand of a convolution backward in one pass over dy: g = dy * act'(yact) (act 0: g = dy, yact unused) is
+ * quantised into a / b as rg_f8_quantize_dual does (either may be NULL) and its per-tile channel sums go to
+ * part[rg_f8_grad_tiles(N, L)][C] (NULL: not wanted; the bias gradient is the column sum of `part`, rg_rows_sum_pair) — replaces
+ * rg_act_bwd + rg_f8_quantize_dual + the channel-sum passes of the reference's autograd (torch Conv2d backward: grad_bias =
+ * grad_output.sum((0, 2, 3))) on the fp8 path; g itself is never written */
+int rg_f8_grad_tiles(int N, int L);
+int rg_f8_quantize_grad(const float* dy, const float* yact, int act, float slope, void* a, void* b, float* part, float* state,
+                        float* scale_out, int fmt, int N, int C, int L, rg_stream_t stream);
 /* y = act(sx*sw * conv(xq, wq) + shift[k] + residual); xq [N][H*W][Cp], wq [K][KH*KW][Cp] (e4m3), sx / sw: the quantiser's scale_out of each operand */
 int rg_conv2d_f8_fwd(const void* xq, const void* wq, const float* sx, const float* sw, int fmt_x, float* y, int N, int C,
                      int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q, const float* shift,

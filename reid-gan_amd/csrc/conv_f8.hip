@@ -43,6 +43,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ int4v bload16(rsrc_t r, unsigned off) {
     return __builtin_bit_cast(int4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
+__device__ __forceinline__ float4 bload4f(rsrc_t r, unsigned off) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float bloadf(rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
@@ -185,10 +190,25 @@ __device__ __forceinline__ unsigned byte_of4(unsigned w0, unsigned w1, unsigned 
     return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
 }
 
+// Gradient variant (yact != NULL and / or part != NULL): the tensor quantised is g = in * act'(yact) — the activation backward of the
+// layer whose output gradient this is, never written out in fp32 — and part[tile][c] (tile = n tile * pixel tiles + pixel tile)
+// receives the tile's sum of g per channel: the bias gradient is the column sum of `part` (rg_rows_sum_pair), fixed order.
+__device__ __forceinline__ float f8_act_grad(float yv, int act, float slope) {      // `act` is uniform: selects, no branches
+    const float neg = act == RG_ACT_LEAKY ? slope : 0.f;
+    const float step = yv > 0.f ? 1.f : neg;
+    return act == RG_ACT_TANH ? 1.f - yv * yv : (act == RG_ACT_NONE ? 1.f : step);
+}
+
+// Loads: every thread reads 16 float4 (one per sample of the tile) through a buffer resource that spans exactly the tile's samples —
+// offsets outside it (samples beyond N, channels beyond C, pixels beyond L) return zeros, so the loads carry no branches and are
+// issued eight samples at a time (the first version tested n / c / l per pass and waited for each load before the next: a
+// 4-workgroup launch took 12 us).  VEC: L % 4 == 0 (one 16-byte load per sample), otherwise four dword loads.
+template <bool VEC, bool HASY>
 __global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __restrict__ in, unsigned char* __restrict__ a,
                                                                unsigned char* __restrict__ b, float* __restrict__ state,
                                                                float* __restrict__ scale_out, int fmt, int N, int C, int L,
-                                                               int Cp, int Np, int xcd_groups) {
+                                                               int Cp, int Np, int xcd_groups, const float* __restrict__ yact,
+                                                               int act, float slope, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) unsigned tile[16 * 16 * 16];        // word (n, lq, c) at ((n*16 + lq)*16 + (c ^ 4*(lq>>2)))
     __shared__ float red[16];
     const int t = threadIdx.x;
@@ -217,27 +237,52 @@ __global__ __launch_bounds__(256) void f8_quantize_dual_kernel(const float* __re
     float m = 0.f;
     const int lq = t & 15, cr = t >> 4;                  // this thread's pixel quad and channel of the tile
     const int c = c0 + cr, l = l0 + 4 * lq;
-    const bool vec = (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-    unsigned wn[16];                                     // word of sample n0 + pass
+    const int nvalid = N - n0 < 16 ? N - n0 : 16;
+    const unsigned sstride = (unsigned)C * (unsigned)L * 4u;              // bytes per sample; 16 of them < 2^31 (host check)
+    const unsigned win = (unsigned)nvalid * sstride;
+    const rsrc_t rin = make_rsrc(in + (int64_t)n0 * C * L, win);
+    const rsrc_t ry = make_rsrc(HASY ? yact + (int64_t)n0 * C * L : in, HASY ? win : 0u);
+    unsigned o0[4];                                                     // VEC: o0[0] only
 #pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-        const int n = n0 + pass;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < N && c < C) {
-            const float* src = in + ((int64_t)n * C + c) * L + l;
-            if (vec && l + 3 < L) {
-                v = *reinterpret_cast<const float4*>(src);
+    for (int j = 0; j < 4; ++j) o0[j] = (c < C && l + j < L) ? ((unsigned)c * (unsigned)L + (unsigned)(l + j)) * 4u : OOB;
+    unsigned wn[16];                                     // word of sample n0 + pass
+    float csum = 0.f;                                    // this thread's share of the channel sum (16 samples x 4 pixels)
+    constexpr int HB = HASY ? 8 : 16;                    // samples whose loads are in flight together (64 VGPRs either way)
+#pragma unroll
+    for (int half = 0; half < 16 / HB; ++half) {
+        float4 vv[HB], yy[HASY ? HB : 1];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const unsigned so = (unsigned)(half * HB + i) * sstride;
+            if (VEC) {
+                vv[i] = bload4f(rin, o0[0] + so);
+                if (HASY) yy[i] = bload4f(ry, o0[0] + so);
             } else {
-                if (l < L) v.x = src[0];
-                if (l + 1 < L) v.y = src[1];
-                if (l + 2 < L) v.z = src[2];
-                if (l + 3 < L) v.w = src[3];
+                vv[i] = make_float4(bloadf(rin, o0[0] + so), bloadf(rin, o0[1] + so), bloadf(rin, o0[2] + so), bloadf(rin, o0[3] + so));
+                if (HASY) yy[i] = make_float4(bloadf(ry, o0[0] + so), bloadf(ry, o0[1] + so), bloadf(ry, o0[2] + so), bloadf(ry, o0[3] + so));
             }
         }
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        wn[pass] = pack4(fminf(fmaxf(v.x * q, -fmax), fmax), fminf(fmaxf(v.y * q, -fmax), fmax),
-                         fminf(fmaxf(v.z * q, -fmax), fmax), fminf(fmaxf(v.w * q, -fmax), fmax), fmt);
-        if (a) tile[(pass * 16 + lq) * 16 + (cr ^ ((lq >> 2) << 2))] = wn[pass];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int pass = half * HB + i;
+            float4 v = vv[i];
+            if (HASY) {
+                v.x *= f8_act_grad(yy[i].x, act, slope);
+                v.y *= f8_act_grad(yy[i].y, act, slope);
+                v.z *= f8_act_grad(yy[i].z, act, slope);
+                v.w *= f8_act_grad(yy[i].w, act, slope);
+            }
+            csum += (v.x + v.y) + (v.z + v.w);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            wn[pass] = pack4(fminf(fmaxf(v.x * q, -fmax), fmax), fminf(fmaxf(v.y * q, -fmax), fmax),
+                             fminf(fmaxf(v.z * q, -fmax), fmax), fminf(fmaxf(v.w * q, -fmax), fmax), fmt);
+            if (a) tile[(pass * 16 + lq) * 16 + (cr ^ ((lq >> 2) << 2))] = wn[pass];
+        }
+    }
+    if (part) {                                          // uniform; the 16 pixel-quad lanes of a channel are 16 consecutive lanes
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) csum += __shfl_xor(csum, o, 64);
+        if (lq == 0 && c < C) part[((int64_t)(n0 >> 4) * ((L + 63) >> 6) + ltile) * C + c] = csum;
     }
     if (b && c < C) {
 #pragma unroll
@@ -732,6 +777,20 @@ extern "C" int rg_f8_quantize(const float* in, void* out, float* state, float* s
     return rg::check_launch("rg_f8_quantize");
 }
 
+static void launch_quantize_dual(hipStream_t stream, unsigned wgs, const float* in, void* a, void* b, float* state, float* scale_out,
+                                 int fmt, int N, int C, int L, int Cp, int Np, int xcd_groups, const float* yact, int act, float slope,
+                                 float* part) {
+    const bool vec = (L & 3) == 0;
+#define RG_QD(V, Y)                                                                                                              \
+    hipLaunchKernelGGL((f8_quantize_dual_kernel<V, Y>), dim3(wgs), dim3(256), 0, stream, in, static_cast<unsigned char*>(a),      \
+                       static_cast<unsigned char*>(b), state, scale_out, fmt, N, C, L, Cp, Np, xcd_groups, yact, act, slope, part)
+    if (vec && yact) RG_QD(true, true);
+    else if (vec) RG_QD(true, false);
+    else if (yact) RG_QD(false, true);
+    else RG_QD(false, false);
+#undef RG_QD
+}
+
 // Both layouts of in[N][C][L] in one pass: a [N][L][Cp] (may be NULL) and b [C][L][Np] (may be NULL); see rg_f8_quantize.
 // Padding rows of `a` beyond C and of `b` beyond N are written as zeros only inside the 16-wide tiles that hold real data; callers
 // allocate exactly Cp = 16*ceil(C/16), Np = 16*ceil(N/16), which those tiles cover.
@@ -744,10 +803,34 @@ extern "C" int rg_f8_quantize_dual(const float* in, void* a, void* b, float* sta
     const int64_t wgs = (int64_t)(xcd_groups ? rg::cdiv(lt, 8) * 8 : lt) * (Cp / 16) * (Np / 16);
     RG_REQUIRE(wgs < (1ll << 31), "rg_f8_quantize_dual: tensor exceeds the grid limit");
     rg::ProfScope prof(rg::FAM_MISC, stream, 0.0, (double)L * (4.0 * N * C + (a ? (double)N * Cp : 0.0) + (b ? (double)C * Np : 0.0)));
-    hipLaunchKernelGGL(f8_quantize_dual_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, in,
-                       static_cast<unsigned char*>(a), static_cast<unsigned char*>(b), state, scale_out, fmt, N, C, L, Cp, Np,
-                       xcd_groups);
+    RG_REQUIRE((int64_t)C * L < (1ll << 24), "rg_f8_quantize_dual: C * L exceeds the 2^31-byte window of one 16-sample tile");
+    launch_quantize_dual(stream, (unsigned)wgs, in, a, b, state, scale_out, fmt, N, C, L, Cp, Np, xcd_groups, nullptr, RG_ACT_NONE, 0.f,
+                         nullptr);
     return rg::check_launch("rg_f8_quantize_dual");
+}
+
+// rows of `part` rg_f8_quantize_grad writes for [N][C][L]: one per (16-sample, 64-pixel) tile
+extern "C" int rg_f8_grad_tiles(int N, int L) { return (pad16(N) / 16) * rg::cdiv(L, 64); }
+
+// The output-gradient operand of a convolution's backward in one pass over dy: g = dy * act'(yact) (yact NULL: g = dy) quantised
+// into a [N][L][Cp] and / or b [C][L][Np] as rg_f8_quantize_dual does, with the per-tile channel sums of g in
+// part[rg_f8_grad_tiles(N, L)][C] (NULL: not wanted).  Neither g nor a separate reduction pass over it touches memory.
+extern "C" int rg_f8_quantize_grad(const float* dy, const float* yact, int act, float slope, void* a, void* b, float* part,
+                                   float* state, float* scale_out, int fmt, int N, int C, int L, hipStream_t stream) {
+    RG_REQUIRE(dy && (a || b || part) && state && (fmt == 0 || fmt == 1) && N > 0 && C > 0 && L > 0, "rg_f8_quantize_grad: bad arguments");
+    RG_REQUIRE(act == RG_ACT_NONE || yact, "rg_f8_quantize_grad: the activation backward needs the forward output");
+    const int Cp = pad16(C), Np = pad16(N);
+    const int lt = rg::cdiv(L, 64);
+    const int xcd_groups = lt >= 16 ? 1 : 0;
+    const int64_t wgs = (int64_t)(xcd_groups ? rg::cdiv(lt, 8) * 8 : lt) * (Cp / 16) * (Np / 16);
+    RG_REQUIRE(wgs < (1ll << 31), "rg_f8_quantize_grad: tensor exceeds the grid limit");
+    const bool has_act = act != RG_ACT_NONE;
+    rg::ProfScope prof(rg::FAM_MISC, stream, 0.0,
+                       (double)L * ((has_act ? 8.0 : 4.0) * N * C + (a ? (double)N * Cp : 0.0) + (b ? (double)C * Np : 0.0)));
+    RG_REQUIRE((int64_t)C * L < (1ll << 24), "rg_f8_quantize_grad: C * L exceeds the 2^31-byte window of one 16-sample tile");
+    launch_quantize_dual(stream, (unsigned)wgs, dy, a, b, state, scale_out, fmt, N, C, L, Cp, Np, xcd_groups, has_act ? yact : nullptr,
+                         act, slope, part);
+    return rg::check_launch("rg_f8_quantize_grad");
 }
 
 // ---- forward: y[N][K][P][Q] fp32 = act(sx * sw * conv(xq, wq) + shift + residual) ------------------------------------

@@ -167,6 +167,23 @@ def quantize_dual(x, state, want_a=True, want_b=True):
     return (QTensor(a, scale, state.fmt) if want_a else None, QTensor(b, scale, state.fmt) if want_b else None)
 
 
+def quantize_grad_dual(dy, state, want_a=True, want_b=True, y=None, act=ops.ACT_NONE, slope=0.0, want_sum=False):
+    """the output gradient of a convolution, ONE pass: g = dy * act'(y) -> (QTensor [N][L][Kp] or None, QTensor [K][L][Np] or None,
+    per-tile channel sums of g [tiles][K] or None).  g is not materialised; sum the partials with ops.rows_sum_pair."""
+    dy, y = _chk(dy, "dy"), _chk(y, "y")
+    if act != ops.ACT_NONE and (y is None or y.shape != dy.shape):
+        raise ValueError("quantize_grad_dual: the activation backward needs the forward output of the same shape")
+    N, C = dy.shape[0], dy.shape[1]
+    L = dy.numel() // (N * C)
+    scale = torch.empty(1, dtype=torch.float32, device=dy.device)
+    a = torch.empty((N, L, pad16(C)), dtype=torch.uint8, device=dy.device) if want_a else None
+    b = torch.empty((C, L, pad16(N)), dtype=torch.uint8, device=dy.device) if want_b else None
+    part = torch.empty((lib.rg_f8_grad_tiles(N, L), C), dtype=torch.float32, device=dy.device) if want_sum else None
+    lib.rg_f8_quantize_grad(_p(dy), _p(y) if act != ops.ACT_NONE else None, act, slope, _p(a), _p(b), _p(part), state.ptr, _p(scale),
+                            state.fmt, N, C, L, _stream())
+    return (QTensor(a, scale, state.fmt) if want_a else None, QTensor(b, scale, state.fmt) if want_b else None, part)
+
+
 class F8Layer(object):
     """Scaling states and the cached quantised filters of one convolution layer."""
 
@@ -189,6 +206,21 @@ class F8Layer(object):
     def quant_grad_both(self, dy, want_nhwc, want_chwn):
         self.sdy.prepare(dy)
         return quantize_dual(dy, self.sdy, want_nhwc, want_chwn)
+
+    def quant_grad_fused(self, dy, y, act, slope, want_nhwc, want_chwn, want_sum):
+        """(dyq, dyq_t, bias gradient or None) of g = dy * act'(y).  With a calibrated delayed scale everything is one launch
+        (+ the column sum of the tile partials for the bias); a scale that has to be measured first needs g itself, so that case
+        runs the activation backward separately and measures it (policy 'jit', first use of the layer)."""
+        measured = self.states.policy == "jit" or not self.sdy.calibrated
+        if measured and act != ops.ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
+            act = ops.ACT_NONE
+        if measured:
+            self.sdy.prepare(dy)
+        if not (want_nhwc or want_chwn or want_sum):
+            return None, None, None
+        a, b, part = quantize_grad_dual(dy, self.sdy, want_nhwc, want_chwn, y=y, act=act, slope=slope, want_sum=want_sum)
+        return a, b, part
 
     def weights(self, w, key=None):
         """(wq [K][RS][Cp], wq_t [C][RS][Kp]) of the filter tensor, re-quantised (always with a fresh amax: filters are

@@ -45,6 +45,23 @@ def _bias_grad(tape, bias, dy):
     tape.add_grad(bias, db)
 
 
+def _f8_backward_operands(tape, f8, bias, dy, y, act, slope, need_dx, want_w):
+    """fp8 backward head shared by the convolution classes: activation backward, e5m2 quantisation in both layouts and the bias
+    gradient from ONE pass over dy (lowp.F8Layer.quant_grad_fused).  An InstanceNorm backward that produced dy has already summed
+    it per (n, c): that shortcut (see _bias_grad) is kept when there is no activation in between."""
+    want_b = tape.wants(bias)
+    inst = getattr(dy, "_rg_inst_sums", None) if act == ACT_NONE else None
+    use_inst = want_b and inst is not None and inst.numel() == dy.shape[0] * dy.shape[1]
+    dyq, dyq_t, part = f8.quant_grad_fused(dy, y, act, slope, need_dx, want_w, want_b and not use_inst)
+    if want_b:
+        if use_inst:
+            db, _ = ops.rows_sum_pair(inst, None, dy.shape[0], dy.shape[1], tape.grad_out(bias), None)
+        else:
+            db, _ = ops.rows_sum_pair(part, None, part.shape[0], part.shape[1], tape.grad_out(bias), None)
+        tape.add_grad(bias, db)
+    return dyq, dyq_t
+
+
 def sn_prepare(convs, training):
     """power iteration + W / sigma of every spectral-normed convolution a network forward is about to run, in two launches instead
     of two per layer; each SNConv2d.tf picks its result up (same u / v updates, same values as the per-layer launches)"""
@@ -141,16 +158,12 @@ class Conv2d(RGModule, _KrscCache):
             if mask_input or dx_channels is not None or want_rowsum:
                 raise NotImplementedError("Conv2d(fp8): mask_input / dx_channels / want_rowsum belong to the fp32 ResNet programs")
             xq_t, y, act, slope, geom = tape.pop()
-            if act != ACT_NONE:
-                dy = ops.act_bwd(dy, y, act, slope)
             want_w = tape.wants(self.weight)
-            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            dyq, dyq_t = _f8_backward_operands(tape, f8, self.bias, dy, y, act, slope, need_dx, want_w)
             if want_w:
                 gout = tape.grad_out(self.weight)
                 tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(xq_t, dyq_t, geom, out=gout), xq_t, dyq_t, gout,
                                                            worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
-            if tape.wants(self.bias):
-                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             _, wq_t = f8.weights(self.weight.detach(), self._wkey())
@@ -241,17 +254,13 @@ class ConvTranspose2d(RGModule, _KrscCache):
         if f8 is not None:
             from . import lowp
             xq_t, y, act, slope, geom = tape.pop()
-            if act != ACT_NONE:
-                dy = ops.act_bwd(dy, y, act, slope)
             want_w = tape.wants(self.weight)
-            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            dyq, dyq_t = _f8_backward_operands(tape, f8, self.bias, dy, y, act, slope, need_dx, want_w)
             if want_w:
                 # filter gradient with the roles swapped: the "input" is dy (e5m2), the "output gradient" is x (e4m3)
                 gout = tape.grad_out(self.weight)
                 tape.add_grad(self.weight, ops.side_call(lambda: lowp.conv_wgrad(dyq_t, xq_t, geom, out=gout), xq_t, dyq_t, gout,
                                                            worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
-            if tape.wants(self.bias):
-                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             wq, _ = f8.weights(self.weight.detach(), self._wkey())
@@ -854,24 +863,22 @@ class SNConv2d(RGModule):
 
     def tb(self, tape, dy, need_dx=True, residual=None):
         x, y, act, slope, w_sn, wk, sigma, u, v = tape.pop()
-        if act != ACT_NONE:
-            dy = ops.act_bwd(dy, y, act, slope)
         f8 = self.__dict__.get("_rg_f8")
         if f8 is not None:
             from . import lowp
             wq_t, geom = wk
             want_w = tape.wants(self.weight_orig)
-            dyq, dyq_t = f8.quant_grad_both(dy, need_dx, want_w)
+            dyq, dyq_t = _f8_backward_operands(tape, f8, self.bias, dy, y, act, slope, need_dx, want_w)
             if want_w:
                 gout = tape.grad_out(self.weight_orig)
                 tape.add_grad(self.weight_orig, ops.side_call(
                     lambda: ops.spectral_norm_bwd(lowp.conv_wgrad(x, dyq_t, geom), w_sn, u, v, sigma, out=gout),
                     x, dyq_t, w_sn, u, v, sigma, gout, worth=ops.side_worth(_geom_gflop(geom, dy), fp8=True)))
-            if tape.wants(self.bias):
-                _bias_grad(tape, self.bias, dy)
             if not need_dx:
                 return None
             return lowp.conv_dgrad(dyq, wq_t, geom, (geom[2], geom[3]), residual=residual)
+        if act != ACT_NONE:
+            dy = ops.act_bwd(dy, y, act, slope)
         if tape.wants(self.weight_orig):
             dw_sn = ops.conv2d_wgrad(x, dy, w_sn.shape, self.stride, self.padding)
             tape.add_grad(self.weight_orig, ops.spectral_norm_bwd(dw_sn, w_sn, u, v, sigma,

@@ -72,6 +72,50 @@ def test_quantizer_bit_exact(dev, fmt, shape):
     assert float(state[0]) == float(amax) and float(state[1]) == float(amax) and float(state[3]) == R.FMAX[fmt]
 
 
+@pytest.mark.parametrize("act", ["none", "leaky", "relu", "tanh"])
+@pytest.mark.parametrize("shape", [(2, 5, 6, 4), (3, 39, 16, 8), (32, 64, 32, 16), (7, 3, 3, 3), (17, 16, 1, 1), (20, 21, 64, 32)])
+def test_gradient_quantizer_fuses_activation_backward_and_bias_sum(dev, act, shape):
+    """rg_f8_quantize_grad: g = dy * act'(y) quantised (e5m2, both layouts) with the channel sums of g, against the CPU emulation
+    applied to the same g: bytes bit-exact (the fused product is the one rg_act_bwd computes), sums at fp32 summation accuracy,
+    collected amax == max|g|."""
+    from rg_hip import lowp, ops
+    g = torch.Generator().manual_seed(sum(shape) + len(act))
+    dy = torch.randn(shape, generator=g) * torch.exp(torch.randn(shape, generator=g) * 2.0)
+    y = torch.randn(shape, generator=g)
+    if act == "tanh":
+        y = torch.tanh(y)
+    code = {"none": ops.ACT_NONE, "leaky": ops.ACT_LEAKY, "relu": ops.ACT_RELU, "tanh": ops.ACT_TANH}[act]
+    slope = 0.2
+    dyd, yd = dy.to(dev), y.to(dev)
+    # g as the stand-alone activation backward (rg_act_bwd) computes it: the fused pass must form the same fp32 products
+    gref = (dyd if act == "none" else ops.act_bwd(dyd, yd, code, slope)).cpu()
+    if act == "relu":
+        assert torch.equal(gref, dy * (y > 0).float())
+    if act == "leaky":
+        assert torch.equal(gref, dy * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)))
+    st, states = _states(dev)
+    s = states[1]                                       # e5m2
+    s.prepare(gref.to(dev))                             # the scale the delayed policy would carry over
+    a, b, part = lowp.quantize_grad_dual(dyd, s, True, True, y=yd, act=code, slope=slope, want_sum=True)
+    torch.cuda.synchronize()
+    xq, d = R.quantize(gref, gref.abs().max(), 1)
+    assert torch.equal(a.buf.cpu(), R.to_layout(xq, "nhwc")), "nhwc bytes differ"
+    assert torch.equal(b.buf.cpu(), R.to_layout(xq, "chwn")), "chwn bytes differ"
+    assert float(a.scale.cpu()) == float(d)
+    N, C = shape[0], shape[1]
+    L = shape[2] * shape[3]
+    assert tuple(part.shape) == (((N + 15) // 16) * ((L + 63) // 64), C)
+    db = part.double().sum(0).cpu()
+    ref = gref.double().sum((0, 2, 3))
+    assert (db - ref).abs().max().item() <= 2e-6 * gref.double().abs().sum((0, 2, 3)).max().item()
+    assert float(s.view().cpu()[1]) == float(gref.abs().max())
+    # sums only / one layout only: same results
+    _, b2, p2 = lowp.quantize_grad_dual(dyd, s, False, True, y=yd, act=code, slope=slope, want_sum=True)
+    assert torch.equal(b2.buf, b.buf) and torch.equal(p2, part)
+    out, _ = ops.rows_sum_pair(part, None, part.shape[0], C)
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-6 * gref.double().abs().sum((0, 2, 3)).max().item()
+
+
 def test_delayed_scaling_rolls_once_per_step(dev):
     """policy 'delayed': the first use calibrates just in time, later uses quantise with the previous step's amax while
     collecting the next one; values beyond the stale range saturate instead of overflowing."""
