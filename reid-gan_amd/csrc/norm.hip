@@ -881,6 +881,179 @@ __global__ __launch_bounds__(256) void bn_train_fwd_fused_kernel(const float* __
     }
 }
 
+// ---- the same two kernels for maps whose rows are float4 multiples, with the loads taken out of the loops ---------------------------
+// One workgroup per channel holds N*HW <= 16384 values = at most 16 float4 per thread.  The loops above issue one load per
+// iteration behind an integer division and wait for it: with two workgroups per CU nothing hides that latency (a [32, 512, 16 x 8]
+// layer: 15 us forward, 1 TB/s).  Here every thread computes its U offsets once (buffer resource over the tensor: offsets past
+// the end return zeros / drop the store, so there are no bounds branches) and issues its loads together:
+//   forward   x (and the residual) are loaded ONCE into registers; mean, centred sum of squares and the output come from them;
+//   backward  two sweeps (the sums, then dx / dres) of U float4 per operand, eight units in flight per sweep.
+// Same per-thread summation order and block reduction as the loop kernels: same statistics.
+typedef __amdgpu_buffer_rsrc_t nrsrc_t;
+constexpr unsigned NOOB = 0x80000000u;                  // tensors are < 2^31 bytes here (host check)
+__device__ __forceinline__ nrsrc_t n_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 n_load4(nrsrc_t r, unsigned off) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void n_store4(nrsrc_t r, unsigned off, float4 v) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), r, off, 0, 0);
+}
+
+template <int U>
+__device__ __forceinline__ void bn_unit_offsets(unsigned (&off)[U], int t, int total, int rl, int C, int c, int HW) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int i = t + 256 * j;
+        const int n = i / rl, v = i - n * rl;            // U divisions per thread, once
+        off[j] = i < total ? (unsigned)((n * C + c) * HW + 4 * v) * 4u : NOOB;
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void bn_train_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ res,
+                                                               float* __restrict__ y, float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, int N, int C, int HW, float eps,
+                                                               float momentum, int act, float slope, unsigned bytes) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int rl = HW >> 2;
+    const int total = N * rl;
+    const float cnt = (float)N * (float)HW;
+    const nrsrc_t rx = n_rsrc(x, bytes), ry = n_rsrc(y, bytes);
+    const nrsrc_t rr = n_rsrc(res ? res : x, res ? bytes : 0u);
+    unsigned off[U];
+    bn_unit_offsets<U>(off, t, total, rl, C, c, HW);
+    float4 a[U], r[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) a[j] = n_load4(rx, off[j]);
+    if (res) {                                           // uniform; in flight behind x while the statistics are formed
+#pragma unroll
+        for (int j = 0; j < U; ++j) r[j] = n_load4(rr, off[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+    const float mu = bn_block_sum(s, red) / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const float d0 = a[j].x - mu, d1 = a[j].y - mu, d2 = a[j].z - mu, d3 = a[j].w - mu;
+        const float e = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        q += off[j] != NOOB ? e : 0.f;
+    }
+    const float m2 = bn_block_sum(q, red);
+    const float var = m2 / cnt;
+    const float is = rsqrtf(var + eps);
+    if (t == 0) {
+        mean_out[c] = mu;
+        invstd_out[c] = is;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (cnt > 1.f ? m2 / (cnt - 1.f) : var);
+    }
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float sh = (beta ? beta[c] : 0.f) - mu * gs;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        float4 o;
+        o.x = a[j].x * gs + sh; o.y = a[j].y * gs + sh; o.z = a[j].z * gs + sh; o.w = a[j].w * gs + sh;
+        if (res) { o.x += r[j].x; o.y += r[j].y; o.z += r[j].z; o.w += r[j].w; }
+        o.x = rg_apply_act(o.x, act, slope); o.y = rg_apply_act(o.y, act, slope);
+        o.z = rg_apply_act(o.z, act, slope); o.w = rg_apply_act(o.w, act, slope);
+        n_store4(ry, off[j], o);
+    }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void bn_train_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ yact, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               float* __restrict__ dx, float* __restrict__ dres,
+                                                               float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat, int N,
+                                                               int C, int HW, int act, float slope, unsigned bytes) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int rl = HW >> 2;
+    const int total = N * rl;
+    const float cnt = (float)N * (float)HW;
+    const float mu = mean[c], is = invstd[c];
+    const bool has_act = act != RG_ACT_NONE;
+    const nrsrc_t rx = n_rsrc(x, bytes), rg = n_rsrc(dy, bytes), ry = n_rsrc(has_act ? yact : dy, has_act ? bytes : 0u);
+    const nrsrc_t rdx = n_rsrc(dx ? dx : dres, dx ? bytes : 0u), rdr = n_rsrc(dres ? dres : dx, dres ? bytes : 0u);
+    unsigned off[U];
+    bn_unit_offsets<U>(off, t, total, rl, C, c, HW);
+    constexpr int B = U < 8 ? U : 8;                     // units in flight per operand
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < U; j0 += B) {
+        float4 g[B], a[B], yv[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            g[j] = n_load4(rg, off[j0 + j]);
+            a[j] = n_load4(rx, off[j0 + j]);
+            if (has_act) yv[j] = n_load4(ry, off[j0 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (has_act) {
+                g[j].x *= act_grad_from_out(yv[j].x, act, slope); g[j].y *= act_grad_from_out(yv[j].y, act, slope);
+                g[j].z *= act_grad_from_out(yv[j].z, act, slope); g[j].w *= act_grad_from_out(yv[j].w, act, slope);
+            }
+            s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+            s2 += (g[j].x * (a[j].x - mu) + g[j].y * (a[j].y - mu)) + (g[j].z * (a[j].z - mu) + g[j].w * (a[j].w - mu));
+        }
+    }
+    s1 = bn_block_sum(s1, red);
+    s2 = bn_block_sum(s2, red) * is;
+    if (t == 0) {
+        sum_dy[c] = s1;
+        sum_dy_xhat[c] = s2;
+    }
+    if (!dx && !dres) return;
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float a0 = s1 / cnt, b0 = s2 / cnt * is;
+#pragma unroll
+    for (int j0 = 0; j0 < U; j0 += B) {
+        float4 g[B], a[B], yv[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            g[j] = n_load4(rg, off[j0 + j]);
+            if (dx) a[j] = n_load4(rx, off[j0 + j]);
+            if (has_act) yv[j] = n_load4(ry, off[j0 + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (has_act) {
+                g[j].x *= act_grad_from_out(yv[j].x, act, slope); g[j].y *= act_grad_from_out(yv[j].y, act, slope);
+                g[j].z *= act_grad_from_out(yv[j].z, act, slope); g[j].w *= act_grad_from_out(yv[j].w, act, slope);
+            }
+            if (dres) n_store4(rdr, off[j0 + j], g[j]);
+            if (dx) {
+                float4 o;
+                o.x = gs * (g[j].x - a0 - (a[j].x - mu) * b0); o.y = gs * (g[j].y - a0 - (a[j].y - mu) * b0);
+                o.z = gs * (g[j].z - a0 - (a[j].z - mu) * b0); o.w = gs * (g[j].w - a0 - (a[j].w - mu) * b0);
+                n_store4(rdx, off[j0 + j], o);
+            }
+        }
+    }
+}
+
+// units (float4) per thread of the register kernels for this geometry, 0 = use the loop kernels
+static int bn_reg_units(int N, int C, int HW) {
+    if ((HW & 3) || (int64_t)N * C * HW * 4 >= (1ll << 31)) return 0;
+    const int total = N * (HW >> 2);
+    const int per = (total + 255) / 256;
+    if (per > 16) return 0;
+    return per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 16;
+}
+
 // g = dy * act'(y); sum_dy[c] = sum g, sum_dy_xhat[c] = sum g * xhat; dx = gamma * invstd * (g - mean(g) - xhat * mean(g xhat)); dres = g
 __global__ __launch_bounds__(256) void bn_train_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ yact, const float* __restrict__ mean,
@@ -994,6 +1167,9 @@ extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, fl
 
 // Train-mode BatchNorm, one launch per direction (see the kernels): rg_bn_train_fused_ok says whether the geometry qualifies;
 // otherwise use rg_bn_stats + rg_bn_apply_fwd / rg_bn_bwd_reduce + rg_bn_bwd_apply.
+// development switch: RG_BN_REG=0 keeps the loop kernels (A/B timing)
+static const bool g_bn_reg = !(getenv("RG_BN_REG") && atoi(getenv("RG_BN_REG")) == 0);
+
 extern "C" size_t rg_bn_train_fused_ok(int N, int C, int HW) {
     return (int64_t)N * HW <= 16384 && C >= 128 ? 1 : 0;
 }
@@ -1004,8 +1180,21 @@ extern "C" int rg_bn_train_fwd_fused(const float* x, const float* gamma, const f
     RG_REQUIRE(x && y && mean && invstd && N > 0 && C > 0 && HW > 0, "rg_bn_train_fwd_fused: bad arguments");
     RG_REQUIRE((int64_t)N * HW < (1ll << 30), "rg_bn_train_fwd_fused: N*HW too large");
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * N * (double)C * HW);
-    hipLaunchKernelGGL(bn_train_fwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd,
-                       running_mean, running_var, N, C, HW, eps, momentum, act, slope);
+    const unsigned bytes = (unsigned)((int64_t)N * C * HW * 4);
+#define RG_BNF(U_)                                                                                                             \
+    hipLaunchKernelGGL(bn_train_fwd_reg_kernel<U_>, dim3(C), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd,   \
+                       running_mean, running_var, N, C, HW, eps, momentum, act, slope, bytes)
+    switch (g_bn_reg ? bn_reg_units(N, C, HW) : 0) {
+        case 1: RG_BNF(1); break;
+        case 2: RG_BNF(2); break;
+        case 4: RG_BNF(4); break;
+        case 8: RG_BNF(8); break;
+        case 16: RG_BNF(16); break;
+        default:
+            hipLaunchKernelGGL(bn_train_fwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, gamma, beta, residual, y, mean, invstd,
+                               running_mean, running_var, N, C, HW, eps, momentum, act, slope);
+    }
+#undef RG_BNF
     return rg::check_launch("rg_bn_train_fwd_fused");
 }
 
@@ -1016,8 +1205,21 @@ extern "C" int rg_bn_train_bwd_fused(const float* x, const float* dy, const floa
     RG_REQUIRE(act == RG_ACT_NONE || y_act, "rg_bn_train_bwd_fused: fused activation needs the forward output");
     RG_REQUIRE((int64_t)N * HW < (1ll << 30), "rg_bn_train_bwd_fused: N*HW too large");
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, ((act ? 12.0 : 8.0) + (dx ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)) * N * (double)C * HW);
-    hipLaunchKernelGGL(bn_train_bwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres, sum_dy,
-                       sum_dy_xhat, N, C, HW, act, slope);
+    const unsigned bytes = (unsigned)((int64_t)N * C * HW * 4);
+#define RG_BNB(U_)                                                                                                             \
+    hipLaunchKernelGGL(bn_train_bwd_reg_kernel<U_>, dim3(C), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres,  \
+                       sum_dy, sum_dy_xhat, N, C, HW, act, slope, bytes)
+    switch (g_bn_reg ? bn_reg_units(N, C, HW) : 0) {
+        case 1: RG_BNB(1); break;
+        case 2: RG_BNB(2); break;
+        case 4: RG_BNB(4); break;
+        case 8: RG_BNB(8); break;
+        case 16: RG_BNB(16); break;
+        default:
+            hipLaunchKernelGGL(bn_train_bwd_fused_kernel, dim3(C), dim3(256), 0, stream, x, dy, y_act, mean, invstd, gamma, dx, dres,
+                               sum_dy, sum_dy_xhat, N, C, HW, act, slope);
+    }
+#undef RG_BNB
     return rg::check_launch("rg_bn_train_bwd_fused");
 }
 
