@@ -1453,6 +1453,53 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
     }
 }
 
+// The same for Ng % 4 == 0 and PIX % 4 == 0 (every layer of the networks here): four consecutive columns per thread — they stay in
+// one image and one row, so partials, residual, mask and output move as float4 — and the partial loads of four splits are in flight
+// together.  Same left-to-right sum over the splits per element: same values as the scalar kernel.
+__global__ __launch_bounds__(256) void conv_splitk_finish_vec_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                     int M, int Ng, int PIX, FastDiv d_pix, FastDiv d_ng4,
+                                                                     int splits, Epilogue ep) {
+    const int ng4 = Ng >> 2;
+    const int64_t total4 = (int64_t)M * ng4;
+    const int64_t sstride4 = total4;                    // float4 units between splits
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = fdiv((int)i, d_ng4);
+        const int n = ((int)i - m * ng4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            const float4 a = p4[(int64_t)s * sstride4 + i], b = p4[(int64_t)(s + 1) * sstride4 + i];
+            const float4 c = p4[(int64_t)(s + 2) * sstride4 + i], d = p4[(int64_t)(s + 3) * sstride4 + i];
+            v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+            v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+        }
+        for (; s < splits; ++s) {
+            const float4 a = p4[(int64_t)s * sstride4 + i];
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const int im = fdiv(n, d_pix);
+        const int pix = n - im * PIX;
+        const int64_t o = ((int64_t)im * M + m) * PIX + pix;
+        if (ep.scale) { const float sc = ep.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        if (ep.shift) { const float sh = ep.shift[m]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+        if (ep.res) {
+            const float4 r = *reinterpret_cast<const float4*>(ep.res + o);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        v.x = rg_apply_act(v.x, ep.act, ep.slope); v.y = rg_apply_act(v.y, ep.act, ep.slope);
+        v.z = rg_apply_act(v.z, ep.act, ep.slope); v.w = rg_apply_act(v.w, ep.act, ep.slope);
+        if (ep.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(ep.mask + o);
+            if (!(mk.x > 0.f)) v.x = 0.f;
+            if (!(mk.y > 0.f)) v.y = 0.f;
+            if (!(mk.z > 0.f)) v.z = 0.f;
+            if (!(mk.w > 0.f)) v.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(out + o) = v;
+    }
+}
+
 // w[K][C][RS] -> wt[K][RS][C]
 __global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __restrict__ wt, int64_t total, int C, int RS) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1747,6 +1794,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     out[m * crs + (int64_t)c * RS + rs] = s;
 }
 
+// n % 4 == 0: 64 float4 outputs x 4 split lanes per workgroup, four slab loads in flight per thread; per element the same summation
+// tree as splitk_reduce_kernel (lane ty adds splits ty, ty + 8, ... and ty + 4, ty + 12, ... in two chains): same values.
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n,
+                                                                int splits, int rsc, int C, int RS) {
+    __shared__ float4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i < n4) {
+        int k = ty;
+        for (; k + 12 < splits; k += 16) {
+            const float4 a = w4[(int64_t)k * n4 + i], b = w4[(int64_t)(k + 4) * n4 + i];
+            const float4 c = w4[(int64_t)(k + 8) * n4 + i], d = w4[(int64_t)(k + 12) * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s0.x += c.x; s0.y += c.y; s0.z += c.z; s0.w += c.w;
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        }
+        for (; k + 4 < splits; k += 8) {
+            const float4 a = w4[(int64_t)k * n4 + i], b = w4[(int64_t)(k + 4) * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (k < splits) {
+            const float4 a = w4[(int64_t)k * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[ty][tx] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (ty != 0 || i >= n4) return;
+    const float4 r0 = red[0][tx], r1 = red[1][tx], r2 = red[2][tx], r3 = red[3][tx];
+    const float4 v = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                                 (r0.w + r1.w) + (r2.w + r3.w));
+    if (!rsc) {
+        reinterpret_cast<float4*>(out)[i] = v;
+        return;
+    }
+    const int64_t crs = (int64_t)C * RS;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t e = i * 4 + j;
+        const int64_t m = e / crs;
+        const int np = (int)(e - m * crs);
+        const int rs = np / C, c = np - rs * C;
+        out[m * crs + (int64_t)c * RS + rs] = vv[j];
+    }
+}
+
 // algorithmic HBM bytes of one conv launch: one read of each operand + one write of the result (fp32)
 #define ALG_BYTES (4.0 * ((double)N * C * H * W + (double)K * C * KH * KW + (double)N * K * P * Q))
 
@@ -1865,6 +1964,36 @@ static unsigned finish_grid(int64_t n) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+static void launch_reduce(hipStream_t stream, const float* ws, float* out, int64_t n, int splits, int rsc, int C, int RS);
+
+// development switch: RG_SPLITK_VEC=0 keeps the scalar finishing / reduction kernels
+static bool splitk_vec() {
+    static const int env = getenv("RG_SPLITK_VEC") ? atoi(getenv("RG_SPLITK_VEC")) : 1;
+    return env != 0;
+}
+
+static void launch_finish(hipStream_t stream, const float* partial, float* out, int M, int Ng, int PIX, const FastDiv& d_pix,
+                          int splits, const Epilogue& ep) {
+    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.res) |
+                      reinterpret_cast<uintptr_t>(ep.mask)) & 15) == 0;
+    if (splitk_vec() && al && (Ng & 3) == 0 && (PIX & 3) == 0 && (int64_t)M * Ng < (1ll << 31)) {
+        hipLaunchKernelGGL(conv_splitk_finish_vec_kernel, dim3(finish_grid((int64_t)M * (Ng >> 2))), dim3(256), 0, stream, partial, out,
+                           M, Ng, PIX, d_pix, make_fastdiv(Ng >> 2), splits, ep);
+        return;
+    }
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)M * Ng)), dim3(256), 0, stream, partial, out, M, Ng, PIX,
+                       d_pix, splits, ep);
+}
+
+static void launch_reduce(hipStream_t stream, const float* ws, float* out, int64_t n, int splits, int rsc, int C, int RS) {
+    const bool al = ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (splitk_vec() && al && (n & 3) == 0)
+        hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)rg::cdiv64(n >> 2, 64)), dim3(256), 0, stream, ws, out, n, splits, rsc,
+                           C, RS);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream, ws, out, n, splits, rsc, C, RS);
+}
+
 // ---- tap-reuse kernel (conv3x3_halo_kernel): geometry test, plan, launch ----
 static bool halo_enabled() {
     static const int env = getenv("RG_CONV_HALO") ? atoi(getenv("RG_CONV_HALO")) : 1;
@@ -1943,8 +2072,7 @@ static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, voi
     }
     if (pl.splits > 1) {
         if (int e = rg::check_launch(op)) return e;
-        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * p.Ng)), dim3(256), 0, stream, p.partial, p.y,
-                           p.M, p.Ng, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+        launch_finish(stream, p.partial, p.y, p.M, p.Ng, H * W, make_fastdiv(H * W), pl.splits, p.ep);
     }
     return rg::check_launch(op);
 }
@@ -2051,8 +2179,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             const dim3 grid(rg::cdiv(p.Ng, 256), slices);
             THIN_DISPATCH(conv_fwd_k1_kernel, grid, stream, t);
             if (int e = rg::check_launch("rg_conv2d_fwd(thin)")) return e;
-            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)K * p.Ng)), dim3(256), 0, stream,
-                               t.partial, y, K, p.Ng, P * Q, p.d_pq, slices, p.ep);
+            launch_finish(stream, t.partial, y, K, p.Ng, P * Q, p.d_pq, slices, p.ep);
             return rg::check_launch("rg_conv2d_fwd(thin finish)");
         }
     }
@@ -2097,8 +2224,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH);
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
-        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * p.Ng)), dim3(256), 0, stream,
-                           p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
+        launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
     }
     return rg::check_launch("rg_conv2d_fwd");
 }
@@ -2280,8 +2406,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     }
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
-        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(finish_grid((int64_t)p.M * ng_max)), dim3(256), 0, stream,
-                           p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+        launch_finish(stream, p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
     }
     return rg::check_launch("rg_conv2d_dgrad");
 }
@@ -2387,8 +2512,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
             THIN_DISPATCH(conv_wgrad_k1_kernel, grid, stream, t);
             if (int e = rg::check_launch("rg_conv2d_wgrad(thin)")) return e;
             const int64_t n = (int64_t)K * p.Ng;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
-                               static_cast<const float*>(workspace), dw, n, slices, 0, C, KH * KW);
+            launch_reduce(stream, static_cast<const float*>(workspace), dw, n, slices, 0, C, KH * KW);
             return rg::check_launch("rg_conv2d_wgrad(thin reduce)");
         }
     }
@@ -2434,8 +2558,7 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
-                               static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
+            launch_reduce(stream, static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
         }
     }
     return rg::check_launch("rg_conv2d_wgrad(reduce)");
