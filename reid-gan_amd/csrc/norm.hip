@@ -1045,6 +1045,125 @@ __global__ __launch_bounds__(256) void bn_train_bwd_reg_kernel(const float* __re
     }
 }
 
+// ---- InstanceNorm2d with the instance in registers (HW % 4 == 0, at most 8 float4 per lane — every map of the networks here up to
+// 128 x 64): the loop kernels above walk the instance three times (twice in the backward) with one load in flight per lane; here
+// each lane loads its U units of every operand together, forms the statistics / sums from registers and writes the results, so
+// the launch costs one memory round trip instead of 3 * U.  Same per-lane order and reductions as the loop kernels: same values.
+template <int LANES, int U>
+__global__ __launch_bounds__(256) void instnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ res,
+                                                               float* __restrict__ y, float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out, int NC, int C, int HW, float eps,
+                                                               int act, float slope, unsigned bytes) {
+    __shared__ float red[4];
+    const int inst = (int)blockIdx.x * (256 / LANES) + (int)threadIdx.x / LANES;
+    if (inst >= NC) return;
+    const int t = (int)threadIdx.x % LANES;
+    const int nv = HW >> 2;
+    const nrsrc_t rx = n_rsrc(x, bytes), ry = n_rsrc(y, bytes), rr = n_rsrc(res ? res : x, res ? bytes : 0u);
+    unsigned off[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) off[j] = t + LANES * j < nv ? ((unsigned)inst * (unsigned)HW + 4u * (unsigned)(t + LANES * j)) * 4u : NOOB;
+    float4 a[U], r[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) a[j] = n_load4(rx, off[j]);
+    if (res) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) r[j] = n_load4(rr, off[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+    const float mu = in_reduce<LANES>(s, red) / (float)HW;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const float d0 = a[j].x - mu, d1 = a[j].y - mu, d2 = a[j].z - mu, d3 = a[j].w - mu;
+        const float e = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        q += off[j] != NOOB ? e : 0.f;
+    }
+    const float is = rsqrtf(in_reduce<LANES>(q, red) / (float)HW + eps);
+    if (t == 0) {
+        mean_out[inst] = mu;
+        invstd_out[inst] = is;
+    }
+    const int c = inst % C;
+    const float gs = (gamma ? gamma[c] : 1.f) * is;
+    const float sh = (beta ? beta[c] : 0.f) - mu * gs;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        float4 o;
+        o.x = a[j].x * gs + sh; o.y = a[j].y * gs + sh; o.z = a[j].z * gs + sh; o.w = a[j].w * gs + sh;
+        if (res) { o.x += r[j].x; o.y += r[j].y; o.z += r[j].z; o.w += r[j].w; }
+        o.x = rg_apply_act(o.x, act, slope); o.y = rg_apply_act(o.y, act, slope);
+        o.z = rg_apply_act(o.z, act, slope); o.w = rg_apply_act(o.w, act, slope);
+        n_store4(ry, off[j], o);
+    }
+}
+
+template <int LANES, int U>
+__global__ __launch_bounds__(256) void instnorm_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ yact, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               float* __restrict__ dx, float* __restrict__ dres,
+                                                               float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
+                                                               float* __restrict__ sum_dx, int NC, int C, int HW, int act,
+                                                               float slope, unsigned bytes) {
+    __shared__ float red[4];
+    const int inst = (int)blockIdx.x * (256 / LANES) + (int)threadIdx.x / LANES;
+    if (inst >= NC) return;
+    const int t = (int)threadIdx.x % LANES;
+    const int nv = HW >> 2;
+    const bool has_act = act != RG_ACT_NONE;
+    const nrsrc_t rx = n_rsrc(x, bytes), rg = n_rsrc(dy, bytes), ry = n_rsrc(has_act ? yact : dy, has_act ? bytes : 0u);
+    const nrsrc_t rdx = n_rsrc(dx ? dx : dres, dx ? bytes : 0u), rdr = n_rsrc(dres ? dres : dx, dres ? bytes : 0u);
+    const float mu = mean[inst], is = invstd[inst];
+    unsigned off[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) off[j] = t + LANES * j < nv ? ((unsigned)inst * (unsigned)HW + 4u * (unsigned)(t + LANES * j)) * 4u : NOOB;
+    float4 g[U], v[U], yv[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        g[j] = n_load4(rg, off[j]);
+        v[j] = n_load4(rx, off[j]);
+        if (has_act) yv[j] = n_load4(ry, off[j]);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        if (has_act) {
+            g[j].x *= act_grad_from_out(yv[j].x, act, slope); g[j].y *= act_grad_from_out(yv[j].y, act, slope);
+            g[j].z *= act_grad_from_out(yv[j].z, act, slope); g[j].w *= act_grad_from_out(yv[j].w, act, slope);
+        }
+        s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s2 += (g[j].x * (v[j].x - mu) + g[j].y * (v[j].y - mu)) + (g[j].z * (v[j].z - mu) + g[j].w * (v[j].w - mu));
+    }
+    s1 = in_reduce<LANES>(s1, red);
+    s2 = in_reduce<LANES>(s2, red) * is;
+    if (t == 0) {
+        sum_dy[inst] = s1;
+        sum_dy_xhat[inst] = s2;
+    }
+    const float gs = (gamma ? gamma[inst % C] : 1.f) * is;
+    const float a = s1 / (float)HW, b = s2 / (float)HW * is;
+    float sdx = 0.f;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        if (dres) n_store4(rdr, off[j], g[j]);
+        if (dx) {
+            float4 o;
+            o.x = gs * (g[j].x - a - (v[j].x - mu) * b); o.y = gs * (g[j].y - a - (v[j].y - mu) * b);
+            o.z = gs * (g[j].z - a - (v[j].z - mu) * b); o.w = gs * (g[j].w - a - (v[j].w - mu) * b);
+            n_store4(rdx, off[j], o);
+            sdx += off[j] != NOOB ? (o.x + o.y) + (o.z + o.w) : 0.f;
+        }
+    }
+    if (sum_dx) {
+        sdx = in_reduce<LANES>(sdx, red);
+        if (t == 0) sum_dx[inst] = sdx;
+    }
+}
+
 // units (float4) per thread of the register kernels for this geometry, 0 = use the loop kernels
 static int bn_reg_units(int N, int C, int HW) {
     if ((HW & 3) || (int64_t)N * C * HW * 4 >= (1ll << 31)) return 0;
@@ -1241,7 +1360,25 @@ extern "C" int rg_instnorm_fwd(const float* x, const float* gamma, const float* 
     RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_fwd: N*C exceeds 2^31");
     const int NC = N * C;
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, (residual ? 12.0 : 8.0) * (double)NC * HW);
-    switch (in_lanes(HW)) {
+    const int lanes = in_lanes(HW);
+    const int per = (HW & 3) ? 0 : ((HW >> 2) + lanes - 1) / lanes;
+    if (g_bn_reg && per >= 1 && per <= 8 && (int64_t)NC * HW * 4 < (1ll << 31)) {
+        const unsigned bytes = (unsigned)((int64_t)NC * HW * 4);
+        const int U = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
+#define RG_INF(L_, U_)                                                                                                             \
+    case L_ * 16 + U_:                                                                                                             \
+        hipLaunchKernelGGL((instnorm_fwd_reg_kernel<L_, U_>), dim3(rg::cdiv(NC, 256 / L_)), dim3(256), 0, stream, x, gamma, beta,    \
+                           residual, y, mean, invstd, NC, C, HW, eps, act, slope, bytes);                                          \
+        break
+        switch (lanes * 16 + U) {
+            RG_INF(16, 1); RG_INF(16, 2); RG_INF(32, 1); RG_INF(32, 2); RG_INF(64, 1); RG_INF(64, 2); RG_INF(64, 4); RG_INF(64, 8);
+            RG_INF(256, 1); RG_INF(256, 2); RG_INF(256, 4); RG_INF(256, 8);
+            default: rg::set_error("rg_instnorm_fwd: no register kernel for %d lanes x %d units", lanes, U); return RG_ERR_INVALID;
+        }
+#undef RG_INF
+        return rg::check_launch("rg_instnorm_fwd");
+    }
+    switch (lanes) {
         case 16: hipLaunchKernelGGL(instnorm_fwd_kernel<16>, dim3(rg::cdiv(NC, 16)), dim3(256), 0, stream, x, gamma, beta, residual, y,
                                     mean, invstd, NC, C, HW, eps, act, slope); break;
         case 32: hipLaunchKernelGGL(instnorm_fwd_kernel<32>, dim3(rg::cdiv(NC, 8)), dim3(256), 0, stream, x, gamma, beta, residual, y,
@@ -1265,7 +1402,25 @@ extern "C" int rg_instnorm_bwd(const float* x, const float* dy, const float* y_a
     RG_REQUIRE((int64_t)N * C < (1ll << 31), "rg_instnorm_bwd: N*C exceeds 2^31");
     const int NC = N * C;
     rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, ((act ? 12.0 : 8.0) + (dx ? 4.0 : 0.0) + (dres ? 4.0 : 0.0)) * (double)NC * HW);
-    switch (in_lanes(HW)) {
+    const int lanes = in_lanes(HW);
+    const int per = (HW & 3) ? 0 : ((HW >> 2) + lanes - 1) / lanes;
+    if (g_bn_reg && per >= 1 && per <= 8 && (int64_t)NC * HW * 4 < (1ll << 31)) {
+        const unsigned bytes = (unsigned)((int64_t)NC * HW * 4);
+        const int U = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
+#define RG_INB(L_, U_)                                                                                                             \
+    case L_ * 16 + U_:                                                                                                             \
+        hipLaunchKernelGGL((instnorm_bwd_reg_kernel<L_, U_>), dim3(rg::cdiv(NC, 256 / L_)), dim3(256), 0, stream, x, dy, y_act,     \
+                           mean, invstd, gamma, dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope, bytes);              \
+        break
+        switch (lanes * 16 + U) {
+            RG_INB(16, 1); RG_INB(16, 2); RG_INB(32, 1); RG_INB(32, 2); RG_INB(64, 1); RG_INB(64, 2); RG_INB(64, 4); RG_INB(64, 8);
+            RG_INB(256, 1); RG_INB(256, 2); RG_INB(256, 4); RG_INB(256, 8);
+            default: rg::set_error("rg_instnorm_bwd: no register kernel for %d lanes x %d units", lanes, U); return RG_ERR_INVALID;
+        }
+#undef RG_INB
+        return rg::check_launch("rg_instnorm_bwd");
+    }
+    switch (lanes) {
         case 16: hipLaunchKernelGGL(instnorm_bwd_kernel<16>, dim3(rg::cdiv(NC, 16)), dim3(256), 0, stream, x, dy, y_act, mean, invstd,
                                     gamma, dx, dres, sum_dy, sum_dy_xhat, sum_dx, NC, C, HW, act, slope); break;
         case 32: hipLaunchKernelGGL(instnorm_bwd_kernel<32>, dim3(rg::cdiv(NC, 8)), dim3(256), 0, stream, x, dy, y_act, mean, invstd,
