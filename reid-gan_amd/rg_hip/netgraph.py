@@ -77,7 +77,8 @@ class _capture_mode(object):
 
     def __enter__(self):
         self.side = ops._SIDE["on"]
-        ops._SIDE["on"] = False
+        if not ops._GRAPH_SIDE:
+            ops._SIDE["on"] = False
         ops.CAPTURING[0] += 1
 
     def __exit__(self, *a):
@@ -118,7 +119,11 @@ def _replay_forward(rec, xs):
 def _tb_and_grads(net, tape, dys, need, params):
     """the body of tape._NetFn.backward: run the backward program and settle the parameter gradients (arena views are assigned,
     everything else is returned); -> (dxs, grads per parameter, [(param, arena view)] assignments made)"""
-    dxs = net.tb(tape, *dys, need_dx=any(need))
+    ops.side_begin()                  # no-op unless RG_GRAPH_SIDE keeps the weight-gradient side stream inside the capture
+    try:
+        dxs = net.tb(tape, *dys, need_dx=any(need))
+    finally:
+        ops.side_join()               # fork / join nodes of the graph: weight gradients are complete from here on
     if not isinstance(dxs, (tuple, list)):
         dxs = (dxs,)
     dxs = tuple(dxs) + (None,) * (len(need) - len(dxs))

@@ -57,6 +57,7 @@ class _Workspace(object):
 
     def __init__(self):
         self.bufs = {}
+        self.pinned = {}
 
     def get(self, nbytes, device):
         key = (device.index, _stream())
@@ -64,6 +65,10 @@ class _Workspace(object):
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self.bufs[key] = buf
+        if CAPTURING[0]:
+            # a captured launch keeps this ADDRESS: the buffer must outlive the graph even if a later, larger request replaces it
+            # in `bufs` (the allocator would otherwise hand the freed block to a live tensor that the replays then overwrite)
+            self.pinned[buf.data_ptr()] = buf
         return buf
 
 
@@ -230,8 +235,15 @@ def side_join():
 _SIDE_MIN_US = float(os.environ.get("RG_SIDE_MIN_US", "25"))
 
 
+_GRAPH_SIDE = os.environ.get("RG_GRAPH_SIDE", "0") == "1"          # captured backward programs keep the side stream (fork / join nodes)
+_GRAPH_SIDE_MIN_US = float(os.environ.get("RG_GRAPH_SIDE_MIN_US", "4"))
+
+
 def side_worth(gflop, fp8=False):
-    return gflop / (0.30 if fp8 else 0.08) >= _SIDE_MIN_US
+    us = gflop / (0.30 if fp8 else 0.08)
+    if CAPTURING[0]:
+        return us >= _GRAPH_SIDE_MIN_US      # the hand-off is recorded once: only the GPU-side concurrency counts
+    return us >= _SIDE_MIN_US
 
 
 def side_call(fn, *operands, worth=True):

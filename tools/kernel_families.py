@@ -17,6 +17,7 @@ FAMILY = {
     "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV,
     "conv_dgrad_smallc_kernel": CONV, "conv_dgrad_smallc_px_kernel": CONV, "conv_fwd_k1_kernel": CONV,
     "conv_wgrad_k1_kernel": CONV, "conv_splitk_finish_kernel": CONV, "splitk_reduce_kernel": CONV,
+    "conv_splitk_finish_vec_kernel": CONV, "splitk_reduce_vec_kernel": CONV,
     "weights_to_krsc_kernel": CONV, "weights_to_ck_kernel": CONV,
     # norm.hip: conv helpers of the folded (frozen-statistics) BatchNorm
     "bn_fold_wgrad_kernel": CONV, "fold_filters_multi_kernel": CONV, "bn_fold_kernel": CONV,
@@ -28,6 +29,7 @@ FAMILY = {
     "bn_bwd_reduce_finalize_kernel": "norm", "bn_bwd_reduce_partial_kernel": "norm", "bn_eval_bwd_fused_kernel": "norm",
     "bn_stats_finalize_kernel": "norm", "bn_stats_partial_kernel": "norm", "bn_train_bwd_fused_kernel": "norm",
     "bn_train_fwd_fused_kernel": "norm", "instnorm_bwd_kernel": "norm", "instnorm_fwd_kernel": "norm",
+    "bn_train_fwd_reg_kernel": "norm", "bn_train_bwd_reg_kernel": "norm", "instnorm_fwd_reg_kernel": "norm", "instnorm_bwd_reg_kernel": "norm",
     "rows_sum_pair_kernel": "norm", "scale_rows_kernel": "norm", "sum_slices_kernel": "norm",
     "bn_stats_from_partials_kernel": "norm", "bn_bwd_from_partials_kernel": "norm",
     # optim.hip
