@@ -283,8 +283,12 @@ int rg_fold_chunk(void);
 int rg_avgpool2d_fwd(const float* x, float* y, int N, int C, int H, int W, int k, rg_stream_t stream);
 int rg_avgpool2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int k, rg_stream_t stream);
 /* nn.ReflectionPad2d(pad) of the Output block, base_function.py:423-443; y is [N,C,H+2pad,W+2pad] */
-int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, rg_stream_t stream);
-int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int pad, rg_stream_t stream);
+/* act (0 none, 1 relu, 2 leaky relu with slope > 0): the element-wise activation the Output block applies in front of the padding
+ * (base_function.py:436-441 `nonlinearity, ReflectionPad2d, conv`), folded in: y = pad(act(x)), dx = act'(x_act) * pad^T(dy) with
+ * x_act the tensor the forward padded (NULL when act == 0); the fused forms need W % 4 == 0, W >= 8, pad <= 3 */
+int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, int act, float slope, rg_stream_t stream);
+int rg_reflection_pad2d_bwd(const float* dy, const float* x_act, float* dx, int N, int C, int H, int W, int pad, int act, float slope,
+                            rg_stream_t stream);
 /* torch.nn.utils.spectral_norm (base_function.py:121-126; every ResDiscriminator conv, networks.py:917-955) on the
  * filter viewed as W[K][M]: training != 0 runs one power iteration in place on u[K], v[M] (eps-clamped norms), then
  * sigma = u.(W v); writes w_sn = W / sigma and sigma[0] = sigma, sigma[1] = 1 / sigma (device, 2 floats); uv_saved (may be NULL,

@@ -103,6 +103,108 @@ __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __res
     }
 }
 
+// The same pair for W % 4 == 0 and pad <= 3 (the Output blocks: pad 1 on 64-channel maps at full resolution, 134 MB at 64 crops),
+// one float4 of an INPUT row per thread, with the element-wise activation in front of the padding folded in:
+//   forward   y = pad(act(x)): the four values go to row h + pad and to the (at most one) mirrored row, the first / last float4 of a
+//             row also writes the mirrored border columns — unaligned 16-byte buffer stores (dword alignment is what they need);
+//   backward  dx = act'(x) * gather(dy): the same rows / columns read back in the scalar kernel's summation order.
+// act'(.) is taken from the sign of x (ReLU / LeakyReLU with a positive slope: sign(act(x)) == sign(x)).
+typedef __amdgpu_buffer_rsrc_t prsrc_t;
+constexpr unsigned POOB = 0x80000000u;
+__device__ __forceinline__ prsrc_t p_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+typedef float pf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 p_load4(prsrc_t r, unsigned off) {
+    const pf4 v = __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float p_load(prsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void p_store4(prsrc_t r, unsigned off, float4 v) {
+    const pf4 w = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), r, off, 0, 0);
+}
+__device__ __forceinline__ void p_store(prsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+}
+__device__ __forceinline__ float pad_act(float v, int act, float slope) {          // uniform act: selects
+    const float neg = act == RG_ACT_LEAKY ? slope : 0.f;
+    return act == RG_ACT_NONE ? v : (v > 0.f ? v : v * neg);
+}
+__device__ __forceinline__ float pad_act_grad(float xv, int act, float slope) {
+    const float neg = act == RG_ACT_LEAKY ? slope : 0.f;
+    return act == RG_ACT_NONE ? 1.f : (xv > 0.f ? 1.f : neg);
+}
+
+// the (at most) three padded rows / columns input index i of an axis of length n feeds: i + pad, and its mirror images
+__device__ __forceinline__ int pad_targets(int i, int n, int pad, int (&t)[3]) {
+    int c = 0;
+    t[c++] = i + pad;
+    if (i >= 1 && i <= pad) t[c++] = pad - i;
+    if (i <= n - 2 && i >= n - 1 - pad) t[c++] = pad + 2 * (n - 1) - i;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void reflect_pad_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                                  int pad, int OH, int OW, int total4, PadDiv d_w4, PadDiv d_h,
+                                                                  int act, float slope, unsigned ybytes) {
+    const prsrc_t ry = p_rsrc(y, ybytes);
+    const int W4 = W >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const int r = pdiv(i, d_w4), w0 = (i - r * W4) << 2;
+        const int nc = pdiv(r, d_h), h = r - nc * H;
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = pad_act(v.x, act, slope); v.y = pad_act(v.y, act, slope); v.z = pad_act(v.z, act, slope); v.w = pad_act(v.w, act, slope);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        int rows[3];
+        const int nr = pad_targets(h, H, pad, rows);
+        for (int a = 0; a < nr; ++a) {
+            const unsigned row = (unsigned)((nc * OH + rows[a]) * OW) * 4u;
+            p_store4(ry, row + (unsigned)(w0 + pad) * 4u, v);
+            if (w0 == 0)                                  // columns pad - w, w = 1 .. pad
+                for (int w = 1; w <= pad; ++w) p_store(ry, row + (unsigned)(pad - w) * 4u, e[w]);
+            if (w0 == W - 4)                              // columns pad + 2 (W - 1) - w, w = W - 1 - pad .. W - 2
+                for (int w = W - 1 - pad; w <= W - 2; ++w) p_store(ry, row + (unsigned)(pad + 2 * (W - 1) - w) * 4u, e[w - w0]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reflect_pad_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xact,
+                                                                  float* __restrict__ dx, int H, int W, int pad, int OH, int OW,
+                                                                  int total4, PadDiv d_w4, PadDiv d_h, int act, float slope,
+                                                                  unsigned dybytes) {
+    const prsrc_t rd = p_rsrc(dy, dybytes);
+    const int W4 = W >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const int r = pdiv(i, d_w4), w0 = (i - r * W4) << 2;
+        const int nc = pdiv(r, d_h), h = r - nc * H;
+        int rows[3];
+        const int nr = pad_targets(h, H, pad, rows);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < nr; ++a) {
+            const unsigned row = (unsigned)((nc * OH + rows[a]) * OW) * 4u;
+            const float4 m = p_load4(rd, row + (unsigned)(w0 + pad) * 4u);
+            const float mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = w0 + j;
+                s[j] += mv[j];
+                if (w >= 1 && w <= pad) s[j] += p_load(rd, row + (unsigned)(pad - w) * 4u);
+                if (w <= W - 2 && w >= W - 1 - pad) s[j] += p_load(rd, row + (unsigned)(pad + 2 * (W - 1) - w) * 4u);
+            }
+        }
+        float4 o = make_float4(s[0], s[1], s[2], s[3]);
+        if (act != RG_ACT_NONE) {
+            const float4 xv = reinterpret_cast<const float4*>(xact)[i];
+            o.x *= pad_act_grad(xv.x, act, slope); o.y *= pad_act_grad(xv.y, act, slope);
+            o.z *= pad_act_grad(xv.z, act, slope); o.w *= pad_act_grad(xv.w, act, slope);
+        }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
 // ---- spectral norm ---------------------------------------------------------------------------------------------
 // One workgroup per weight matrix W[K][M] (discriminator filters: K <= 128, M <= 2048, <= 1 MB).
 // training: v <- normalize(W^T u), u <- normalize(W v) (one power iteration, eps-clamped norms, as
@@ -252,23 +354,47 @@ extern "C" int rg_avgpool2d_bwd(const float* dy, float* dx, int N, int C, int H,
     return rg::check_launch("rg_avgpool2d_bwd");
 }
 
-extern "C" int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, hipStream_t stream) {
+// y = pad(act(x)); act: RG_ACT_NONE / RELU / LEAKY (the activation the Output block applies in front of its padding)
+extern "C" int rg_reflection_pad2d_fwd(const float* x, float* y, int N, int C, int H, int W, int pad, int act, float slope,
+                                       hipStream_t stream) {
     RG_REQUIRE(x && y && N > 0 && C > 0 && pad >= 0 && pad < H && pad < W, "rg_reflection_pad2d_fwd: pad must be < H and W");
+    RG_REQUIRE(act == RG_ACT_NONE || act == RG_ACT_RELU || (act == RG_ACT_LEAKY && slope > 0.f),
+               "rg_reflection_pad2d_fwd: fused activation must be none, relu or leaky relu with a positive slope");
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * OH * OW;
-    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    RG_REQUIRE(total < (1ll << 31) - (1 << 22), "rg_reflection_pad2d_fwd: more than 2^31 elements");
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 4.0 * (total + (double)N * C * H * W));
+    RG_REQUIRE(total < (1ll << 29) - (1 << 22), "rg_reflection_pad2d_fwd: more than 2^29 elements");
+    const bool vec = (W & 3) == 0 && pad <= 3 && W >= 8 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) {
+        const int64_t total4 = (int64_t)N * C * H * (W >> 2);
+        hipLaunchKernelGGL(reflect_pad_fwd_vec_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, (int)total4,
+                           make_paddiv(W >> 2), make_paddiv(H), act, slope, (unsigned)(total * 4));
+        return rg::check_launch("rg_reflection_pad2d_fwd");
+    }
+    RG_REQUIRE(act == RG_ACT_NONE, "rg_reflection_pad2d_fwd: the fused activation needs W %% 4 == 0, W >= 8 and pad <= 3");
     hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, y, H, W, pad, OH, OW, (int)total,
                        make_paddiv(OW), make_paddiv(OH));
     return rg::check_launch("rg_reflection_pad2d_fwd");
 }
 
-extern "C" int rg_reflection_pad2d_bwd(const float* dy, float* dx, int N, int C, int H, int W, int pad, hipStream_t stream) {
+// dx = act'(x_act) * pad^T(dy); x_act: the tensor the forward padded (needed when act != RG_ACT_NONE)
+extern "C" int rg_reflection_pad2d_bwd(const float* dy, const float* x_act, float* dx, int N, int C, int H, int W, int pad, int act,
+                                       float slope, hipStream_t stream) {
     RG_REQUIRE(dy && dx && N > 0 && C > 0 && pad >= 0 && pad < H && pad < W, "rg_reflection_pad2d_bwd: pad must be < H and W");
+    RG_REQUIRE(act == RG_ACT_NONE || (x_act && (act == RG_ACT_RELU || (act == RG_ACT_LEAKY && slope > 0.f))),
+               "rg_reflection_pad2d_bwd: fused activation must be none, relu or leaky relu with a positive slope, and needs x");
     const int OH = H + 2 * pad, OW = W + 2 * pad;
     const int64_t total = (int64_t)N * C * H * W;
-    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * total);
-    RG_REQUIRE((int64_t)N * C * OH * OW < (1ll << 31) - (1 << 22), "rg_reflection_pad2d_bwd: more than 2^31 elements");
+    rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 4.0 * ((act != RG_ACT_NONE ? 2.0 : 1.0) * total + (double)N * C * OH * OW));
+    RG_REQUIRE((int64_t)N * C * OH * OW < (1ll << 29) - (1 << 22), "rg_reflection_pad2d_bwd: more than 2^29 elements");
+    const bool vec = (W & 3) == 0 && pad <= 3 && W >= 8 && (((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x_act)) & 15) == 0);
+    if (vec) {
+        const int64_t total4 = total >> 2;
+        hipLaunchKernelGGL(reflect_pad_bwd_vec_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, dy, x_act, dx, H, W, pad, OH, OW,
+                           (int)total4, make_paddiv(W >> 2), make_paddiv(H), act, slope, (unsigned)((int64_t)N * C * OH * OW * 4));
+        return rg::check_launch("rg_reflection_pad2d_bwd");
+    }
+    RG_REQUIRE(act == RG_ACT_NONE, "rg_reflection_pad2d_bwd: the fused activation needs W %% 4 == 0, W >= 8 and pad <= 3");
     hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, H, W, pad, OH, OW, (int)total,
                        make_paddiv(W), make_paddiv(H));
     return rg::check_launch("rg_reflection_pad2d_bwd");

@@ -507,12 +507,23 @@ class Output(RGModule):
         act, slope = self._act
         n, pad, conv = self._ix
         m = self.model
-        a = _NormActConv.pre_tf(tape, m[n] if n is not None else None, act, slope, x)
-        return m[conv].tf(tape, m[pad].tf(tape, a), act=ACT_TANH)
+        fused = n is None and ops.reflection_pad_fusable(x, m[pad].padding, act, slope)
+        if fused:
+            # act -> pad as ONE pass over the 64-channel full-resolution map (the separate activation pass and its saved copy go)
+            y = m[conv].tf(tape, ops.reflection_pad2d_fwd(x, m[pad].padding, act, slope), act=ACT_TANH)
+        else:
+            a = _NormActConv.pre_tf(tape, m[n] if n is not None else None, act, slope, x)
+            y = m[conv].tf(tape, m[pad].tf(tape, a), act=ACT_TANH)
+        tape.push((fused, x if fused else None))
+        return y
 
     def tb(self, tape, dy, need_dx=True):
         act, slope = self._act
         n, pad, conv = self._ix
         m = self.model
-        d = m[pad].tb(tape, m[conv].tb(tape, dy))
+        fused, x = tape.pop()
+        d = m[conv].tb(tape, dy)
+        if fused:
+            return ops.reflection_pad2d_bwd(d, m[pad].padding, x, act, slope)
+        d = m[pad].tb(tape, d)
         return _NormActConv.pre_tb(tape, m[n] if n is not None else None, act, slope, d)

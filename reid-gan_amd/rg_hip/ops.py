@@ -716,20 +716,29 @@ def avgpool2d_bwd(dy, x_shape, k=2):
     return dx
 
 
-def reflection_pad2d_fwd(x, pad):
+def reflection_pad_fusable(x, pad, act, slope):
+    """can rg_reflection_pad2d_* fold this activation in? (ReLU / LeakyReLU with a positive slope, float4 rows, pad <= 3)"""
+    return (act == ACT_RELU or (act == ACT_LEAKY and slope > 0.0)) and x.shape[3] % 4 == 0 and x.shape[3] >= 8 and pad <= 3
+
+
+def reflection_pad2d_fwd(x, pad, act=ACT_NONE, slope=0.0):
+    """pad(act(x)) in one pass"""
     x = _chk(x, "x")
     N, C, H, W = x.shape
     y = torch.empty((N, C, H + 2 * pad, W + 2 * pad), dtype=torch.float32, device=x.device)
-    lib.rg_reflection_pad2d_fwd(_p(x), _p(y), N, C, H, W, pad, _stream())
+    lib.rg_reflection_pad2d_fwd(_p(x), _p(y), N, C, H, W, pad, act, slope, _stream())
     return y
 
 
-def reflection_pad2d_bwd(dy, pad):
-    dy = _chk(dy, "dy")
+def reflection_pad2d_bwd(dy, pad, x_act=None, act=ACT_NONE, slope=0.0):
+    """act'(x_act) * pad^T(dy) in one pass (x_act: what the forward padded; only with act)"""
+    dy, x_act = _chk(dy, "dy"), _chk(x_act, "x_act")
     N, C, OH, OW = dy.shape
     H, W = OH - 2 * pad, OW - 2 * pad
+    if act != ACT_NONE and (x_act is None or tuple(x_act.shape) != (N, C, H, W)):
+        raise ValueError("reflection_pad2d_bwd: the fused activation backward needs the forward input [N, C, H, W]")
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
-    lib.rg_reflection_pad2d_bwd(_p(dy), _p(dx), N, C, H, W, pad, _stream())
+    lib.rg_reflection_pad2d_bwd(_p(dy), _p(x_act) if act != ACT_NONE else None, _p(dx), N, C, H, W, pad, act, slope, _stream())
     return dx
 
 

@@ -477,6 +477,33 @@ def test_avgpool_reflection_pad(dev):
     _close(ops.reflection_pad2d_bwd(dy.to(dev), 1), xr.grad, name="reflect bwd wide")
 
 
+@pytest.mark.parametrize("shape,pad", [((2, 3, 8, 8), 1), ((3, 5, 6, 12), 2), ((2, 4, 5, 16), 3), ((4, 64, 32, 16), 1), ((1, 2, 4, 8), 3)])
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+def test_reflection_pad_float4_rows_with_the_activation_folded_in(dev, shape, pad, act):
+    """pad(act(x)) and act'(x) * pad^T(dy) in one pass each (the Output block's nonlinearity -> ReflectionPad2d, base_function.py:
+    436-441) against torch: values are copies / exact products, so equality is exact for the forward; the backward sums up to nine
+    gradient entries per element in the scalar kernel's order."""
+    from rg_hip import ops
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    x = torch.randn(shape, generator=g)
+    code = {"none": ops.ACT_NONE, "relu": ops.ACT_RELU, "leaky": ops.ACT_LEAKY}[act]
+    slope = 0.2
+    xr = x.clone().requires_grad_(True)
+    a = xr if act == "none" else (torch.relu(xr) if act == "relu" else F.leaky_relu(xr, slope))
+    yr = F.pad(a, (pad,) * 4, mode="reflect")
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    assert ops.reflection_pad_fusable(x, pad, code, slope) == (act != "none")
+    y = ops.reflection_pad2d_fwd(x.to(dev), pad, code, slope)
+    assert torch.equal(y.cpu(), yr.detach()), "forward differs"
+    dx = ops.reflection_pad2d_bwd(dy.to(dev), pad, x.to(dev) if act != "none" else None, code, slope)
+    _close(dx, xr.grad, tol=1e-6, name="reflect bwd (fused act)")
+    # the scalar fallback of the narrow maps still refuses a fused activation loudly
+    if act != "none":
+        with pytest.raises(RuntimeError):
+            ops.reflection_pad2d_fwd(torch.randn(1, 1, 4, 6).to(dev), 1, code, slope)
+
+
 @pytest.mark.parametrize("shape", [(32, 3, 3, 3), (64, 32, 4, 4), (1, 128, 1, 1), (128, 128, 4, 4)])
 def test_spectral_norm(dev, shape):
     """torch.nn.utils.spectral_norm (one power iteration per training forward) — weight, u, v and the gradient."""
