@@ -62,6 +62,10 @@ CONV_CASES = [
     (3, 64, 18, 10, 3, 3, 3, 1, 0),      # dual_gan Output conv: 64 -> 3 on the reflection-padded map (direct kernels, 3 channels)
     (2, 37, 11, 9, 2, 3, 3, 2, 1),       # 2 output channels, stride 2, ragged slices
     (2, 130, 12, 8, 4, 3, 3, 1, 1),      # 4 output channels
+    (2, 33, 16, 12, 2, 3, 3, 1, 1),      # four-pixel thin kernels (Q % 4 == 0): 2 output channels, pad 1, ragged channel slices
+    (1, 64, 34, 18, 3, 3, 3, 1, 0),      # Output conv on a 32 x 16 map (valid convolution of the padded 34 x 18 input)
+    (3, 8, 6, 8, 1, 3, 3, 1, 1),         # one output channel, 8 channels, fewer pixel quads than one workgroup
+    (5, 20, 10, 20, 3, 3, 3, 1, 1),      # pixel count not a multiple of the wgrad slice
     # 3x3 / 1 / 1 with channels % 16 == 0 and power-of-two widths: the tap-reuse kernels (one halo tile for all nine taps)
     (2, 64, 64, 32, 64, 3, 3, 1, 1),     # layer1-like: 4 rows of 32 per tile, 64-row tile
     (2, 128, 32, 16, 128, 3, 3, 1, 1),   # layer2-like: 8 rows of 16

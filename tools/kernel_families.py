@@ -17,7 +17,7 @@ FAMILY = {
     "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV,
     "conv_dgrad_smallc_kernel": CONV, "conv_dgrad_smallc_px_kernel": CONV, "conv_fwd_k1_kernel": CONV,
     "conv_wgrad_k1_kernel": CONV, "conv_splitk_finish_kernel": CONV, "splitk_reduce_kernel": CONV,
-    "conv_splitk_finish_vec_kernel": CONV, "splitk_reduce_vec_kernel": CONV,
+    "conv_splitk_finish_vec_kernel": CONV, "splitk_reduce_vec_kernel": CONV, "conv_wgrad_k1_px4_kernel": CONV,
     "weights_to_krsc_kernel": CONV, "weights_to_ck_kernel": CONV,
     # norm.hip: conv helpers of the folded (frozen-statistics) BatchNorm
     "bn_fold_wgrad_kernel": CONV, "fold_filters_multi_kernel": CONV, "bn_fold_kernel": CONV,
@@ -55,7 +55,7 @@ FAMILY = {
     "bgemm_kernel": "misc", "softmax_rows_bwd_kernel": "misc", "softmax_rows_fwd_kernel": "misc",
     "attn_fwd_kernel": "misc", "attn_bwd_kernel": "misc",
     "avgpool_bwd_kernel": "misc", "avgpool_fwd_kernel": "misc", "reflect_pad_bwd_kernel": "misc",
-    "reflect_pad_fwd_kernel": "misc", "scale_by_device_scalar_kernel": "misc", "spectral_norm_bwd_apply_kernel": "misc",
+    "reflect_pad_fwd_kernel": "misc", "reflect_pad_fwd_vec_kernel": "misc", "reflect_pad_bwd_vec_kernel": "misc", "scale_by_device_scalar_kernel": "misc", "spectral_norm_bwd_apply_kernel": "misc",
     "spectral_norm_bwd_kernel": "misc", "spectral_norm_dot_partial_kernel": "misc", "spectral_norm_power_kernel": "misc",
     "spectral_norm_power_multi_kernel": "misc", "spectral_norm_scale_multi_kernel": "misc",
     "bicubic_norm_bwd_kernel": "misc", "bicubic_norm_fwd_kernel": "misc",
