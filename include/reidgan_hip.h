@@ -126,6 +126,10 @@ int rg_instnorm_fwd(const float* x, const float* gamma, const float* beta, const
 int rg_instnorm_bwd(const float* x, const float* dy, const float* y_act, const float* mean, const float* invstd,
                     const float* gamma, float* dx, float* dres, float* sum_dy, float* sum_dy_xhat, float* sum_dx, int N, int C,
                     int HW, int act, float slope, rg_stream_t stream);
+/* out[c] = sum_{n, pixels} dy[n][c][.] in one launch (the bias gradient of torch's Conv2d / Linear backward, grad_output.sum over
+ * every axis but the channel) when rg_channel_sum_ok says so — at most 32768 values per channel; larger maps use rg_bn_bwd_reduce */
+size_t rg_channel_sum_ok(int N, int C, int HW);
+int rg_channel_sum(const float* dy, float* out, int N, int C, int HW, rg_stream_t stream);
 /* out_a[c] = sum_n a[n][c], out_b[c] = sum_n b[n][c]: dgamma / dbeta of an affine InstanceNorm2d (torch.nn.InstanceNorm2d
  * backward as used by CC/dual_gan/models/base_function.py:38-49) from the per-(n,c) sums of rg_bn_bwd_reduce. */
 int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C, rg_stream_t stream);

@@ -688,6 +688,45 @@ __global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __re
     out[i] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) * (sa[0] * sb[0]);
 }
 
+// n % 4 == 0: float4 outputs, four slab loads in flight; per element the summation tree of f8_splitk_reduce_kernel
+__global__ __launch_bounds__(256) void f8_splitk_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n,
+                                                                   int splits, const float* __restrict__ sa,
+                                                                   const float* __restrict__ sb) {
+    __shared__ float4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n4 = n >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i < n4) {
+        int k = ty;
+        for (; k + 12 < splits; k += 16) {
+            const float4 a = w4[(int64_t)k * n4 + i], b = w4[(int64_t)(k + 4) * n4 + i];
+            const float4 c = w4[(int64_t)(k + 8) * n4 + i], d = w4[(int64_t)(k + 12) * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s0.x += c.x; s0.y += c.y; s0.z += c.z; s0.w += c.w;
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        }
+        for (; k + 4 < splits; k += 8) {
+            const float4 a = w4[(int64_t)k * n4 + i], b = w4[(int64_t)(k + 4) * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (k < splits) {
+            const float4 a = w4[(int64_t)k * n4 + i];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[ty][tx] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (ty != 0 || i >= n4) return;
+    const float4 r0 = red[0][tx], r1 = red[1][tx], r2 = red[2][tx], r3 = red[3][tx];
+    const float sc = sa[0] * sb[0];
+    reinterpret_cast<float4*>(out)[i] = make_float4(((r0.x + r1.x) + (r2.x + r3.x)) * sc, ((r0.y + r1.y) + (r2.y + r3.y)) * sc,
+                                                    ((r0.z + r1.z) + (r2.z + r3.z)) * sc, ((r0.w + r1.w) + (r2.w + r3.w)) * sc);
+}
+
 static bool fits(int64_t bytes) { return bytes > 0 && bytes < (1ll << 31); }
 
 static void fill_geom(F8P& p, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P, int Q) {
@@ -981,7 +1020,11 @@ extern "C" int rg_conv2d_f8_wgrad(const void* xq, const void* dyq, const float* 
     RG_F8_LAUNCH(2, grid);
     if (int e = rg::check_launch("rg_conv2d_f8_wgrad")) return e;
     const int64_t n = (int64_t)p.M * p.Ng;
-    hipLaunchKernelGGL(f8_splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
-                       static_cast<const float*>(workspace), dw, n, splits, sdy, sx);
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+        hipLaunchKernelGGL(f8_splitk_reduce_vec_kernel, dim3((unsigned)rg::cdiv64(n >> 2, 64)), dim3(256), 0, stream,
+                           static_cast<const float*>(workspace), dw, n, splits, sdy, sx);
+    else
+        hipLaunchKernelGGL(f8_splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream,
+                           static_cast<const float*>(workspace), dw, n, splits, sdy, sx);
     return rg::check_launch("rg_conv2d_f8_wgrad(reduce)");
 }

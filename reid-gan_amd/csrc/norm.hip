@@ -1164,6 +1164,44 @@ __global__ __launch_bounds__(256) void instnorm_bwd_reg_kernel(const float* __re
     }
 }
 
+// out[c] = sum over n and the pixels of dy[n][c][.] — the bias gradient of a convolution / linear layer — in ONE launch when a
+// channel holds at most 32768 values (one workgroup per channel; eight loads in flight per thread; fixed order).  The two-stage
+// slice reduction (rg_bn_bwd_reduce on unit statistics) stays for the large maps.
+template <bool VEC>
+__global__ __launch_bounds__(256) void channel_sum_small_kernel(const float* __restrict__ dy, float* __restrict__ out, int N, int C,
+                                                                int HW, unsigned bytes) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int rl = VEC ? HW >> 2 : HW;
+    const int total = N * rl;
+    const nrsrc_t rg = n_rsrc(dy, bytes);
+    float s = 0.f;
+    for (int i0 = t; i0 < total; i0 += 256 * 8) {
+        unsigned off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + 256 * j;
+            const int n = i / rl, v = i - n * rl;
+            off[j] = i < total ? (unsigned)((n * C + c) * HW + (VEC ? 4 * v : v)) * 4u : NOOB;
+        }
+        if (VEC) {
+            float4 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = n_load4(rg, off[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+        } else {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off[j], 0, 0));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += a[j];
+        }
+    }
+    s = bn_block_sum(s, red);
+    if (t == 0) out[c] = s;
+}
+
 // units (float4) per thread of the register kernels for this geometry, 0 = use the loop kernels
 static int bn_reg_units(int N, int C, int HW) {
     if ((HW & 3) || (int64_t)N * C * HW * 4 >= (1ll << 31)) return 0;
@@ -1274,6 +1312,23 @@ __global__ __launch_bounds__(256) void rows_sum_pair_kernel(const float* __restr
         if (a) oa[c] = ta;
         if (b) ob[c] = tb;
     }
+}
+
+// 1 when rg_channel_sum runs as one launch for this geometry (else use rg_bn_bwd_reduce on unit statistics)
+extern "C" size_t rg_channel_sum_ok(int N, int C, int HW) {
+    return (int64_t)N * HW <= 32768 && (int64_t)N * C * HW * 4 < (1ll << 31) ? 1 : 0;
+}
+
+extern "C" int rg_channel_sum(const float* dy, float* out, int N, int C, int HW, hipStream_t stream) {
+    RG_REQUIRE(dy && out && N > 0 && C > 0 && HW > 0, "rg_channel_sum: bad arguments");
+    RG_REQUIRE(rg_channel_sum_ok(N, C, HW), "rg_channel_sum: %d x %d values per channel need the two-stage reduction", N, HW);
+    rg::ProfScope prof(rg::FAM_NORM, stream, 0.0, 4.0 * N * (double)C * HW);
+    const unsigned bytes = (unsigned)((int64_t)N * C * HW * 4);
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL(channel_sum_small_kernel<true>, dim3(C), dim3(256), 0, stream, dy, out, N, C, HW, bytes);
+    else
+        hipLaunchKernelGGL(channel_sum_small_kernel<false>, dim3(C), dim3(256), 0, stream, dy, out, N, C, HW, bytes);
+    return rg::check_launch("rg_channel_sum");
 }
 
 extern "C" int rg_rows_sum_pair(const float* a, const float* b, float* out_a, float* out_b, int N, int C,

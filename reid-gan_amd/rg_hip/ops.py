@@ -537,6 +537,10 @@ def channel_sum(dy, out=None):
     """sum over N and HW of dy[N][C][HW] (bias gradient)."""
     dy = _chk(dy, "dy")
     N, C, HW = _nchw(dy)
+    if _ws_query("rg_channel_sum_ok", N, C, HW):
+        s = out if out is not None else torch.empty(C, dtype=torch.float32, device=dy.device)
+        lib.rg_channel_sum(_p(dy), _p(s), N, C, HW, _stream())
+        return s
     s, _ = bn_bwd_reduce(dy, dy, None, const_fill(C, 0.0, dy.device), const_fill(C, 1.0, dy.device), out_sum_dy=out)
     return s
 

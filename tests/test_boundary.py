@@ -37,11 +37,13 @@ def test_queries_and_error_convention_without_gpu():
     queries = {"rg_conv2d_fwd_workspace": (32, 64, 64, 3, 3, 64, 32), "rg_conv2d_dgrad_workspace": (32, 64, 64, 32, 64, 3, 3, 1, 1),
                "rg_conv2d_wgrad_workspace": (32, 64, 64, 3, 3, 64, 32), "rg_bn_workspace": (32, 64, 2048),
                "rg_bn_train_fused_ok": (64, 1024, 128), "rg_conv2d_f8_wgrad_workspace": (32, 64, 64, 3, 3, 64, 32),
-               "rg_spectral_norm_bwd_workspace": (256, 2304), "rg_loss_workspace": ()}
+               "rg_spectral_norm_bwd_workspace": (256, 2304), "rg_loss_workspace": (), "rg_channel_sum_ok": (64, 256, 128)}
     assert sorted(queries) == sorted(n for n, (ret, _) in protos.items() if ret == "size_t")
     for name, a in queries.items():
         assert getattr(lib, name)(*a) >= 0, name
     assert lib.rg_bn_train_fused_ok(64, 1024, 128) == 1 and lib.rg_bn_train_fused_ok(64, 64, 2048) == 0
+    assert lib.rg_channel_sum_ok(64, 256, 128) == 1 and lib.rg_channel_sum_ok(32, 64, 2048) == 0
+    assert lib.rg_f8_grad_tiles(17, 65) == 4        # a plain count, not a status: 2 sample tiles x 2 pixel tiles
     with pytest.raises(RuntimeError) as e:
         lib.rg_fill(None, 4, 1.0, None)
     assert "rg_fill" in str(e.value)

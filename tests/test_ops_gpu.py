@@ -481,6 +481,20 @@ def test_avgpool_reflection_pad(dev):
     _close(ops.reflection_pad2d_bwd(dy.to(dev), 1), xr.grad, name="reflect bwd wide")
 
 
+@pytest.mark.parametrize("shape", [(64, 256, 128, 1), (5, 7, 3, 3), (32, 64, 32, 16), (3, 130, 1, 1), (64, 48, 32, 16), (32, 64, 64, 32)])
+def test_channel_sum_one_launch_and_two_stage(dev, shape):
+    """bias gradients: sum over n and the pixels; one launch up to 32768 values per channel, the slice reduction above that"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    dy = torch.randn(shape, generator=g)
+    ref = dy.double().sum((0, 2, 3))
+    out = ops.channel_sum(dy.to(dev))
+    scale = dy.double().abs().sum((0, 2, 3)).max().item()
+    assert (out.double().cpu() - ref).abs().max().item() <= 2e-6 * scale
+    buf = torch.full((shape[1],), 7.0).to(dev)
+    assert ops.channel_sum(dy.to(dev), out=buf) is buf and torch.equal(buf, out)
+
+
 @pytest.mark.parametrize("shape,pad", [((2, 3, 8, 8), 1), ((3, 5, 6, 12), 2), ((2, 4, 5, 16), 3), ((4, 64, 32, 16), 1), ((1, 2, 4, 8), 3)])
 @pytest.mark.parametrize("act", ["none", "relu", "leaky"])
 def test_reflection_pad_float4_rows_with_the_activation_folded_in(dev, shape, pad, act):

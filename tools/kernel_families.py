@@ -23,13 +23,13 @@ FAMILY = {
     "bn_fold_wgrad_kernel": CONV, "fold_filters_multi_kernel": CONV, "bn_fold_kernel": CONV,
     # conv_f8.hip
     "conv_f8_kernel": CONV_F8, "f8_amax_kernel": CONV_F8, "f8_quantize_dual_kernel": CONV_F8,
-    "f8_quantize_transpose_kernel": CONV_F8, "f8_roll_kernel": CONV_F8, "f8_splitk_reduce_kernel": CONV_F8,
+    "f8_quantize_transpose_kernel": CONV_F8, "f8_roll_kernel": CONV_F8, "f8_splitk_reduce_kernel": CONV_F8, "f8_splitk_reduce_vec_kernel": CONV_F8,
     # norm.hip
     "act_bwd_sum_kernel": "norm", "bn_apply_fwd_kernel": "norm", "bn_bwd_apply_kernel": "norm",
     "bn_bwd_reduce_finalize_kernel": "norm", "bn_bwd_reduce_partial_kernel": "norm", "bn_eval_bwd_fused_kernel": "norm",
     "bn_stats_finalize_kernel": "norm", "bn_stats_partial_kernel": "norm", "bn_train_bwd_fused_kernel": "norm",
     "bn_train_fwd_fused_kernel": "norm", "instnorm_bwd_kernel": "norm", "instnorm_fwd_kernel": "norm",
-    "bn_train_fwd_reg_kernel": "norm", "bn_train_bwd_reg_kernel": "norm", "instnorm_fwd_reg_kernel": "norm", "instnorm_bwd_reg_kernel": "norm",
+    "bn_train_fwd_reg_kernel": "norm", "channel_sum_small_kernel": "norm", "bn_train_bwd_reg_kernel": "norm", "instnorm_fwd_reg_kernel": "norm", "instnorm_bwd_reg_kernel": "norm",
     "rows_sum_pair_kernel": "norm", "scale_rows_kernel": "norm", "sum_slices_kernel": "norm",
     "bn_stats_from_partials_kernel": "norm", "bn_bwd_from_partials_kernel": "norm",
     # optim.hip
