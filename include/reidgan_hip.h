@@ -164,6 +164,11 @@ int rg_dropout_clocked(const float* x, float* y, int64_t n, float p, unsigned lo
 int rg_l2norm_rows_fwd(const float* x, float* y, float* norm, int rows, int D, float eps, rg_stream_t stream);
 int rg_l2norm_rows_bwd(const float* y, const float* dy, const float* norm, float* dx, int rows, int D, float eps,
                        rg_stream_t stream);
+/* F.normalize(x, dim=1) of a feature MAP [N][C][HW] (unit norm over the channels at every pixel; the `gan_x` output of the
+ * cluster-contrast ResNet in train mode, CC/clustercontrast/models/resnet.py:100-107) and its backward; norm is [N][HW] */
+int rg_l2norm_channels_fwd(const float* x, float* y, float* norm, int N, int C, int HW, float eps, rg_stream_t stream);
+int rg_l2norm_channels_bwd(const float* y, const float* dy, const float* norm, float* dx, int N, int C, int HW, float eps,
+                           rg_stream_t stream);
 /* torch.cat along channels / its backward slices, FD/fdgan/model.py:160-161, networks.py:175 */
 int rg_copy_channels(const float* src, float* dst, int N, int Cc, int HW, int Cs, int sc0, int Cd, int dc0,
                      int accumulate, rg_stream_t stream);

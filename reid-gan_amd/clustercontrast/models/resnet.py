@@ -107,12 +107,9 @@ class ResNet(RGModule):
 
     @staticmethod
     def _normalize_map(fmap):
-        """F.normalize(gan_x, dim=1) for [N, C, H, W]: unit L2 norm over channels at every pixel, computed as row
-        normalisation of the [N*H*W, C] view (the permutes are data movement only)."""
-        N, C, H, W = fmap.shape
-        rows = fmap.permute(0, 2, 3, 1).reshape(N * H * W, C)
-        y, nrm = ops.l2norm_rows_fwd(rows)
-        return y.view(N, H, W, C).permute(0, 3, 1, 2).contiguous(), nrm
+        """F.normalize(gan_x, dim=1) for [N, C, H, W]: unit L2 norm over the channels at every pixel, in place of layout (one
+        kernel on the NCHW map; a row view would cost two permuted copies of the 2048-channel map per step)."""
+        return ops.l2norm_channels_fwd(fmap)
 
     def tb(self, tape, d_bn, d_gan=None, need_dx=True):
         rec = tape.pop()
@@ -141,11 +138,7 @@ class ResNet(RGModule):
                 dy = self.feat.tb(tape, dy)
             if d_gan is not None and gan_rec is not None:
                 gan, gnorm = gan_rec
-                N, C, H, W = fshape
-                g_rows = d_gan.permute(0, 2, 3, 1).reshape(N * H * W, C)
-                y_rows = gan.permute(0, 2, 3, 1).reshape(N * H * W, C)
-                d_rows = ops.l2norm_rows_bwd(y_rows, g_rows, gnorm)
-                d_fmap_extra = d_rows.view(N, H, W, C).permute(0, 3, 1, 2).contiguous()
+                d_fmap_extra = ops.l2norm_channels_bwd(gan, d_gan, gnorm)
         d_fmap = self.gap.tb(tape, dy.reshape(dy.shape[0], -1, 1, 1))
         if d_fmap_extra is not None:
             d_fmap = ops.add(d_fmap, d_fmap_extra)

@@ -670,6 +670,25 @@ def l2norm_rows_bwd(y, dy, norm, eps=1e-12):
     return dx
 
 
+def l2norm_channels_fwd(x, eps=1e-12):
+    """F.normalize(x, dim=1) of [N, C, H, W] -> (y, norm [N, H*W]) without permuted copies"""
+    x = _chk(x, "x")
+    N, C, HW = _nchw(x)
+    y = torch.empty_like(x)
+    norm = torch.empty((N, HW), dtype=torch.float32, device=x.device)
+    lib.rg_l2norm_channels_fwd(_p(x), _p(y), _p(norm), N, C, HW, eps, _stream())
+    return y, norm
+
+
+def l2norm_channels_bwd(y, dy, norm, eps=1e-12):
+    y, dy = _chk(y, "y"), _chk(dy, "dy")
+    _same_size("l2norm_channels_bwd", y, dy=dy)
+    N, C, HW = _nchw(y)
+    dx = torch.empty_like(y)
+    lib.rg_l2norm_channels_bwd(_p(y), _p(dy), _p(norm), _p(dx), N, C, HW, eps, _stream())
+    return dx
+
+
 def copy_channels(src, dst, c_count, src_c0, dst_c0, accumulate=False):
     src, dstc = _chk(src, "src"), dst
     if not dst.is_contiguous():

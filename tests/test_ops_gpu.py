@@ -495,6 +495,25 @@ def test_channel_sum_one_launch_and_two_stage(dev, shape):
     assert ops.channel_sum(dy.to(dev), out=buf) is buf and torch.equal(buf, out)
 
 
+@pytest.mark.parametrize("shape", [(4, 2048, 16, 8), (3, 37, 5, 7), (2, 8, 1, 1), (5, 130, 9, 9)])
+def test_l2norm_over_channels_of_a_map(dev, shape):
+    """F.normalize(x, dim=1) of [N, C, H, W] and its backward on the NCHW map itself (resnet.py:100-107 `gan_x`)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    x[0, :, 0, 0] = 0.0                                 # a zero vector: norm clamps to eps, output 0, gradient dy / eps
+    xr = x.double().requires_grad_(True)
+    yr = F.normalize(xr, dim=1)
+    dy = torch.randn(shape, generator=g)
+    dy[0, :, 0, 0] = 0.0
+    yr.backward(dy.double())
+    y, nrm = ops.l2norm_channels_fwd(x.to(dev))
+    _close(y, yr, name="l2norm channels fwd")
+    _close(nrm.view(shape[0], shape[2], shape[3]), x.double().norm(dim=1), name="norms")
+    dx = ops.l2norm_channels_bwd(y, dy.to(dev), nrm)
+    _close(dx, xr.grad, tol=5e-5, name="l2norm channels bwd")
+
+
 @pytest.mark.parametrize("shape,pad", [((2, 3, 8, 8), 1), ((3, 5, 6, 12), 2), ((2, 4, 5, 16), 3), ((4, 64, 32, 16), 1), ((1, 2, 4, 8), 3)])
 @pytest.mark.parametrize("act", ["none", "relu", "leaky"])
 def test_reflection_pad_float4_rows_with_the_activation_folded_in(dev, shape, pad, act):
