@@ -84,6 +84,10 @@ int rg_conv2d_dgrad(const float* dy, const float* w, const float* w_krsc, float*
 int rg_conv2d_dgrad_rowsum_cols(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH, int PW, int P,
                                 int Q);
 int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, int KH, int KW, rg_stream_t stream);
+/* the same re-layout for every filter of a network in ONE launch: `table` (device memory) holds `count` entries of 6 int64 words
+ * {w, w_krsc, K, C, KH*KW, first block}, filters are cut into blocks of rg_krsc_chunk() elements, total_blocks = sum of the blocks */
+int rg_krsc_chunk(void);
+int rg_weights_to_krsc_multi(const void* table, int count, int total_blocks, rg_stream_t stream);
 /* development knob: pin the fwd/dgrad planner's tile (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x256) and split-K count;
  * (-1, -1) releases it (same effect as the RG_CONV_FORCE="tile,splits" environment variable) */
 int rg_conv_set_force(int tile, int splits);

@@ -1595,6 +1595,31 @@ __global__ void weights_to_krsc_kernel(const float* __restrict__ w, float* __res
     }
 }
 
+// The re-layout of EVERY filter of a network in one launch (the per-filter launches were 57 per step of the joint trainer, 5 us
+// each, after every optimizer step).  Table in device memory, 6 int64 words per filter: w, wt, K, C, RS, first block; KRSC_CHUNK
+// elements per workgroup.
+constexpr int KRSC_CHUNK = 2048;
+__global__ __launch_bounds__(256) void weights_to_krsc_multi_kernel(const long long* __restrict__ tab, int count) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[(int64_t)mid * 6 + 5] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = tab + (int64_t)lo * 6;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    float* wt = reinterpret_cast<float*>(e[1]);
+    const int C = (int)e[3], RS = (int)e[4];
+    const int64_t total = e[2] * C * RS;
+    const int64_t beg = ((long long)blockIdx.x - e[5]) * KRSC_CHUNK;
+    for (int64_t i = beg + threadIdx.x; i < beg + KRSC_CHUNK && i < total; i += 256) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int rs = (int)(t % RS);
+        const int64_t k = t / RS;
+        wt[i] = w[(k * C + c) * RS + rs];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient: dw[K][C*KH*KW] = dy[K][N*P*Q] x im2col(x)^T; the reduction (output pixels) is split across
 // blockIdx.z, partial tiles go to a workspace and a second kernel sums them.  Lanes run along the reduction axis
@@ -2536,6 +2561,17 @@ extern "C" int rg_weights_to_krsc(const float* w, float* w_krsc, int K, int C, i
     hipLaunchKernelGGL(weights_to_krsc_kernel, dim3(finish_grid(total)), dim3(256), 0, stream, w, w_krsc, total, C,
                        KH * KW);
     return rg::check_launch("rg_weights_to_krsc");
+}
+
+extern "C" int rg_krsc_chunk(void) { return KRSC_CHUNK; }
+
+// table: device memory, `count` entries of 6 int64 words {w, w_krsc, K, C, KH*KW, first block}; blocks of rg_krsc_chunk() elements
+extern "C" int rg_weights_to_krsc_multi(const void* table, int count, int total_blocks, hipStream_t stream) {
+    RG_REQUIRE(table && count > 0 && total_blocks > 0, "rg_weights_to_krsc_multi: bad arguments");
+    rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 0.0, 8.0 * (double)total_blocks * KRSC_CHUNK);
+    hipLaunchKernelGGL(weights_to_krsc_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const long long*>(table),
+                       count);
+    return rg::check_launch("rg_weights_to_krsc_multi");
 }
 
 namespace {

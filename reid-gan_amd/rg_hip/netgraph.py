@@ -80,6 +80,7 @@ class _capture_mode(object):
         if not ops._GRAPH_SIDE:
             ops._SIDE["on"] = False
         ops.CAPTURING[0] += 1
+        ops.CAPTURE_GEN[0] += 1
 
     def __exit__(self, *a):
         ops.CAPTURING[0] -= 1

@@ -76,18 +76,103 @@ def sn_prepare(convs, training):
 
 
 class _KrscCache(object):
-    """[K][KH*KW][C] copy of a filter tensor for the (r,s)-major kernels, rebuilt only when the weights changed."""
+    """[K][KH*KW][C] copy of a filter tensor for the (r,s)-major kernels, rebuilt only when the weights changed.  Convolutions of one
+    network share a KrscGroup (group_krsc): the first stale member re-lays ALL of them out in one launch."""
+
+    def _krsc_wanted(self):
+        w = self.weight
+        return not (w.shape[2] * w.shape[3] == 1 or w.shape[1] % 4 != 0)
+
+    def _krsc_key(self):
+        w = self.weight
+        arena = getattr(w, "_rg_arena", None)          # the fused optimizers bump their own arena's epoch
+        return (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
 
     def _krsc(self):
-        w = self.weight
-        if w.shape[2] * w.shape[3] == 1 or w.shape[1] % 4 != 0:
+        if not self._krsc_wanted():
             return None
-        arena = getattr(w, "_rg_arena", None)          # the fused optimizers bump their own arena's epoch
-        key = (arena.epoch if arena is not None else WEIGHT_EPOCH[0], w._version, w.data_ptr())
+        grp = self.__dict__.get("_krsc_group")
+        if grp is not None:
+            return grp.get(self)
+        key = self._krsc_key()
         if getattr(self, "_wk_key", None) != key or ops.CAPTURING[0]:
-            self._wk = ops.weights_to_krsc(w.detach())
+            self._wk = ops.weights_to_krsc(self.weight.detach())
             self._wk_key = key
         return self._wk
+
+
+class KrscGroup(object):
+    """The (r,s)-major filter copies of every plain convolution of one network, refreshed together by ONE launch
+    (`rg_weights_to_krsc_multi`) when the first member finds its copy stale — after an optimizer step every member is.  The copies
+    are persistent buffers; the device table is rebuilt when a parameter moved (load_state_dict, .to())."""
+
+    def __init__(self, candidates):
+        self.members = []                 # the candidates that actually asked for their copy (folded convolutions never do)
+        self.ptrs = None
+        self.table = None
+        self.blocks = 0
+        self.cap_gen = -1
+        for m in candidates:
+            m.__dict__["_krsc_group"] = self
+
+    def _build(self):
+        chunk = ops.lib.rg_krsc_chunk()
+        rows, first = [], 0
+        for m in self.members:
+            w = m.weight
+            K, C, RS = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            wk = m.__dict__.get("_wk")
+            if wk is None or tuple(wk.shape) != (K, RS, C) or wk.device != w.device:
+                wk = m._wk = torch.empty((K, RS, C), dtype=torch.float32, device=w.device)
+            rows.append([w.data_ptr(), wk.data_ptr(), K, C, RS, first])
+            first += (K * C * RS + chunk - 1) // chunk
+        dev = self.members[0].weight.device
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.blocks = first
+        self.ptrs = tuple(m.weight.data_ptr() for m in self.members)
+
+    def refresh(self):
+        if self.ptrs != tuple(m.weight.data_ptr() for m in self.members):
+            if ops.CAPTURING[0]:
+                raise RuntimeError("KrscGroup: a parameter moved while a network program is being captured")
+            self._build()
+        ops.lib.rg_weights_to_krsc_multi(ops._p(self.table), len(self.members), self.blocks, ops._stream())
+        for m in self.members:
+            m._wk_key = m._krsc_key()
+
+    def get(self, m):
+        if not m.__dict__.get("_krsc_member"):
+            if ops.CAPTURING[0]:
+                raise RuntimeError("KrscGroup: a convolution asked for its (r,s)-major filters for the first time inside a capture")
+            m.__dict__["_krsc_member"] = True
+            self.members.append(m)
+            self.ptrs = None              # table rebuilt by the refresh below (the new member's key is stale)
+        if ops.CAPTURING[0]:
+            if self.cap_gen != ops.CAPTURE_GEN[0]:       # once per captured program: the refresh is one of its nodes
+                self.refresh()
+                self.cap_gen = ops.CAPTURE_GEN[0]
+        elif m.__dict__.get("_wk_key") != m._krsc_key():
+            self.refresh()
+        return m._wk
+
+
+_KRSC_GROUPS = __import__("os").environ.get("RG_KRSC_GROUP", "1") != "0"      # A/B switch: 0 = one re-layout launch per filter
+
+
+def group_krsc(net):
+    """give the plain convolutions of `net` one shared KrscGroup (idempotent; called on a network's first run)"""
+    if net.__dict__.get("_krsc_grouped"):
+        return
+    net.__dict__["_krsc_grouped"] = True
+    if not _KRSC_GROUPS:
+        return
+    root = net if isinstance(net, nn.Module) else getattr(net, "net", None)     # tape programs over another module's layers
+    if not isinstance(root, nn.Module):
+        return
+    members = [m for m in root.modules() if isinstance(m, _KrscCache) and isinstance(getattr(m, "weight", None), torch.Tensor)
+               and m.weight.is_cuda and m._krsc_wanted() and "_krsc_group" not in m.__dict__]
+    if len(members) >= 2:
+        KrscGroup(members)
 
 
 class Conv2d(RGModule, _KrscCache):

@@ -17,6 +17,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 
 
 _DEV = [None]
+CAPTURE_GEN = [0]    # one number per capture (rg_hip.netgraph): "already refreshed inside THIS capture" for grouped caches
 CAPTURING = [0]      # > 0 while rg_hip.netgraph captures a network program: caches refresh unconditionally (their launches are recorded)
 
 

@@ -146,6 +146,9 @@ def run(net, *xs):
     need_graph = grad_on and (len(params) > 0 or any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs))
     if not need_graph:
         return net.tf(Tape(param_grad=False, record=False), *xs)
+    if "_krsc_grouped" not in net.__dict__:
+        from . import nn as _rnn
+        _rnn.group_krsc(net)              # one re-layout launch per optimizer step for all filters of the network
     if net.__dict__.get("_rg_graph", False):
         # small-kernel networks: forward / backward programs replayed as two single-stream hipGraphs (rg_hip.netgraph)
         from . import netgraph

@@ -18,7 +18,7 @@ FAMILY = {
     "conv_dgrad_smallc_kernel": CONV, "conv_dgrad_smallc_px_kernel": CONV, "conv_fwd_k1_kernel": CONV,
     "conv_wgrad_k1_kernel": CONV, "conv_splitk_finish_kernel": CONV, "splitk_reduce_kernel": CONV,
     "conv_splitk_finish_vec_kernel": CONV, "splitk_reduce_vec_kernel": CONV, "conv_wgrad_k1_px4_kernel": CONV,
-    "weights_to_krsc_kernel": CONV, "weights_to_ck_kernel": CONV,
+    "weights_to_krsc_kernel": CONV, "weights_to_krsc_multi_kernel": CONV, "weights_to_ck_kernel": CONV,
     # norm.hip: conv helpers of the folded (frozen-statistics) BatchNorm
     "bn_fold_wgrad_kernel": CONV, "fold_filters_multi_kernel": CONV, "bn_fold_kernel": CONV,
     # conv_f8.hip
