@@ -739,7 +739,12 @@ def test_dgrad_rowsum(dev, case):
                                               ((2, 3, 51, 43), False, "none"),      # 2193: one workgroup, scalar loads
                                               ((4, 8, 1, 50), False, "leaky"),      # token maps [B, C, L]
                                               ((3, 7, 16, 8), True, "leaky"),       # 128 elements: 16 lanes per instance, 4 per wave
-                                              ((5, 9, 3, 3), True, "none")])        # 9 elements, scalar loads, ragged instance count
+                                              ((5, 9, 3, 3), True, "none"),         # 9 elements, scalar loads, ragged instance count
+                                              ((2, 4, 64, 32), True, "leaky"),      # 2048: 64 lanes x 8 float4 in registers
+                                              ((1, 3, 128, 64), True, "relu"),      # 8192: one workgroup x 8 float4 per thread
+                                              ((3, 5, 8, 8), False, "none"),        # 64: 16 lanes x 1
+                                              ((2, 4, 16, 16), True, "leaky"),      # 256: 32 lanes x 2
+                                              ((2, 2, 256, 128), True, "none")])    # 32768: beyond the register kernels (loop kernel)
 def test_instance_norm_single_launch(dev, shape, affine, act):
     """rg_instnorm_fwd / rg_instnorm_bwd against torch's instance_norm in fp64: output, statistics, dx, residual gradient, the
     per-instance sums behind dgamma / dbeta, and the per-instance sums of dx (bias gradient of the convolution in front)."""
@@ -810,7 +815,12 @@ def test_spectral_norm_multi_equals_per_layer(dev):
 
 @pytest.mark.parametrize("shape,act", [((8, 256, 16, 8), "relu"),       # float4 rows, layer3-like
                                        ((5, 130, 7, 3), "leaky"),       # scalar rows, ragged channel count
-                                       ((64, 2048), "none")])           # BatchNorm1d on [N, C] features
+                                       ((64, 2048), "none"),            # BatchNorm1d on [N, C] features
+                                       ((16, 128, 16, 8), "leaky"),     # register kernels: 2 float4 per thread
+                                       ((32, 128, 16, 8), "relu"),      # 4
+                                       ((16, 128, 32, 16), "none"),     # 8
+                                       ((32, 128, 32, 16), "relu"),     # 16 (the largest one-launch geometry)
+                                       ((7, 128, 12, 20), "leaky")])    # ragged: 420 float4 per channel
 def test_batchnorm_train_single_launch(dev, shape, act):
     """rg_bn_train_fwd_fused / rg_bn_train_bwd_fused against torch.nn.functional.batch_norm (training) in fp64: output, batch
     statistics, running-statistics update, dx, residual gradient, dgamma / dbeta — and bit-compatible tape records with the
