@@ -374,6 +374,11 @@ int rg_l1_fwd(const float* a, const float* b, const int64_t* row_labels, float* 
               void* workspace, size_t workspace_bytes, rg_stream_t stream);
 int rg_l1_bwd(const float* a, const float* b, const int64_t* row_labels, const float* grad_out, const float* out2,
               float* da, float* db, int rows, int64_t inner, float grad_scale, rg_stream_t stream);
+/* per-sample form: out[r] = mean_i |a[r][i] - b[r][i]| — nn.L1Loss(reduction='none')(a, b).flatten(1).mean(-1), the `loss_rec` of
+ * AEModel.get_loss_G(need_cm=True), CC/dual_gan/models/AE_model.py:366 — and its backward from the per-row cotangent */
+int rg_l1_rows_fwd(const float* a, const float* b, float* out, int rows, int64_t inner, rg_stream_t stream);
+int rg_l1_rows_bwd(const float* a, const float* b, const float* grad_rows, float* da, float* db, int rows, int64_t inner,
+                   rg_stream_t stream);
 /* F.cross_entropy(scale*logits, labels, reduction='none'), FD/fdgan/model.py:189, CC/.../cm.py:134-135 */
 int rg_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_rows, float* lse, int B, int K,
                       float scale, rg_stream_t stream);

@@ -475,12 +475,19 @@ class OAEModel(object):
         self.loss_D = (real + fake) * 0.5
         self.loss_D.backward()
 
-    def get_loss_G(self):
-        """need_cm=False branch (:355-376): L1 map * lambda_rec and lsgan map * lambda_g, each averaged."""
+    def get_loss_G(self, need_cm=False, cluster_features=None):
+        """:355-376.  need_cm=False: L1 map * lambda_rec and lsgan map * lambda_g, each averaged.  need_cm=True (:361-372): the same
+        objective formed per sample first (`flatten(1).mean(-1)` of both maps, then the mean over the batch) plus `loss_rec`, the
+        per-sample mean |net_G(cluster_features, pose) - source| of nn.L1Loss(reduction='none') (:122), not weighted."""
         for p in self.net_D.parameters():
             p.requires_grad = False
         app = (self.fake_image - self.source_image).abs() * self.lambda_rec
         ad = o_lsgan(self.net_D(self.fake_image), True, False) * self.lambda_g
+        if need_cm:
+            cluster_image = self.net_G(cluster_features, self.source_pose)
+            loss_rec = (cluster_image - self.source_image).abs().flatten(1).mean(dim=-1)
+            self.loss_G = (app.flatten(1).mean(dim=-1) + ad.flatten(1).mean(dim=-1)).mean()
+            return self.loss_G, loss_rec
         self.loss_G = app.mean() + ad.mean()
         return self.loss_G
 

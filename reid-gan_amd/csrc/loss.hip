@@ -149,6 +149,32 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
     }
 }
 
+// out[r] = mean_i |a[r][i] - b[r][i]| (nn.L1Loss(reduction='none')(a, b).flatten(1).mean(-1)); one workgroup per row
+__global__ __launch_bounds__(256) void l1_rows_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ out, int64_t inner) {
+    __shared__ float red[16];
+    const float* ar = a + (int64_t)blockIdx.x * inner;
+    const float* br = b + (int64_t)blockIdx.x * inner;
+    float s = 0.f;
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < inner; i += 256) s += fabsf(ar[i] - br[i]);
+    s = rg_block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s / (float)inner;
+}
+
+// da[r][i] = sign(a - b) * g[r] / inner, db = -da (either may be NULL)
+__global__ void l1_rows_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                   float* __restrict__ da, float* __restrict__ db, int64_t n, int64_t inner) {
+    const float inv = 1.f / (float)inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gr = g[i / inner] * inv;
+        const float d = a[i] - b[i];
+        const float v = d > 0.f ? gr : (d < 0.f ? -gr : 0.f);
+        if (da) da[i] = v;
+        if (db) db[i] = -v;
+    }
+}
+
 // per-row cross entropy of scale*logits; one workgroup per row; also stores logsumexp for the backward
 __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels,
                                                              float* __restrict__ loss, float* __restrict__ lse, int K,
@@ -328,6 +354,22 @@ extern "C" int rg_l1_bwd(const float* a, const float* b, const int64_t* row_labe
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, row_labels, grad_out, out2 + 1, da,
                        db, n, inner, grad_scale);
     return rg::check_launch("rg_l1_bwd");
+}
+
+extern "C" int rg_l1_rows_fwd(const float* a, const float* b, float* out, int rows, int64_t inner, hipStream_t stream) {
+    RG_REQUIRE(a && b && out && rows > 0 && inner > 0, "rg_l1_rows_fwd: bad arguments");
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 8.0 * rows * (double)inner);
+    hipLaunchKernelGGL(l1_rows_fwd_kernel, dim3(rows), dim3(256), 0, stream, a, b, out, inner);
+    return rg::check_launch("rg_l1_rows_fwd");
+}
+
+extern "C" int rg_l1_rows_bwd(const float* a, const float* b, const float* grad_rows, float* da, float* db, int rows, int64_t inner,
+                              hipStream_t stream) {
+    RG_REQUIRE(a && b && grad_rows && (da || db) && rows > 0 && inner > 0, "rg_l1_rows_bwd: bad arguments");
+    const int64_t n = (int64_t)rows * inner;
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 16.0 * n);
+    hipLaunchKernelGGL(l1_rows_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, grad_rows, da, db, n, inner);
+    return rg::check_launch("rg_l1_rows_bwd");
 }
 
 extern "C" int rg_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_rows, float* lse, int B, int K,

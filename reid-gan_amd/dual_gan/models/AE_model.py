@@ -247,10 +247,15 @@ class AEModel(BaseModel):
         self.loss_G = self.loss_G.detach()
 
     def get_loss_G(self, group_size=None, cf_temp=0.2, need_cm=True, cluster_features=None):
-        if need_cm:
-            raise NotImplementedError("get_loss_G(need_cm=True) (per-sample reconstruction of cluster features) is used "
-                                      "only by commented-out trainer variants")
         self.loss_G = self._loss_G_mean()
+        if need_cm:
+            # synthesize from the cluster features and report its per-sample reconstruction error (AE_model.py:361-372); the
+            # generator objective itself is the same mean as without it
+            if cluster_features is None:
+                raise TypeError("get_loss_G(need_cm=True) needs cluster_features (the reference fails inside net_G without them)")
+            cluster_image = self.net_G(cluster_features, self.source_pose)
+            loss_rec = RF.l1_loss_rows(cluster_image, self.source_image)
+            return self.loss_G, loss_rec
         return self.loss_G
 
     def get_L1_loss(self, with_dis=False):

@@ -85,6 +85,24 @@ def l1_loss(a, b, row_labels=None):
     return _L1.apply(a, b, row_labels)
 
 
+class _L1Rows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.l1_rows_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da, db = ops.l1_rows_bwd(a, b, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return da, db
+
+
+def l1_loss_rows(a, b):
+    """nn.L1Loss(reduction='none')(a, b).flatten(1).mean(-1): one mean absolute difference per sample"""
+    return _L1Rows.apply(a, b)
+
+
 class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, scale):

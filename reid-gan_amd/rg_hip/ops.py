@@ -1038,6 +1038,24 @@ def l1_bwd(a, b, row_labels, grad_out, out2, need_a=True, need_b=True, grad_scal
     return da, db
 
 
+def l1_rows_fwd(a, b):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    _same_size("l1_rows_fwd", a, b=b)
+    rows = a.shape[0]
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    lib.rg_l1_rows_fwd(_p(a), _p(b), _p(out), rows, a.numel() // rows, _stream())
+    return out
+
+
+def l1_rows_bwd(a, b, grad_rows, need_a=True, need_b=True):
+    a, b, grad_rows = _chk(a, "a"), _chk(b, "b"), _chk(grad_rows, "grad_rows")
+    rows = a.shape[0]
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(a) if need_b else None
+    lib.rg_l1_rows_bwd(_p(a), _p(b), _p(grad_rows), _p(da), _p(db), rows, a.numel() // rows, _stream())
+    return da, db
+
+
 def softmax_ce_fwd(logits, labels, scale=1.0):
     logits = _chk(logits, "logits")
     labels = _chk(labels, "labels", torch.int64)

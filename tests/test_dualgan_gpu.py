@@ -197,6 +197,34 @@ def test_aemodel_gan_step(dev):
     model.update_learning_rate()
 
 
+def test_aemodel_get_loss_G_with_cluster_reconstruction(dev):
+    """AEModel.get_loss_G(need_cm=True, cluster_features=...) — the reference's default arguments (AE_model.py:355-372): the generator
+    objective and the per-sample reconstruction error of the image synthesised from the cluster features, with gradients."""
+    model, omodel, D = _ae_pair(dev)
+    inp = D.synth_dualgan_inputs(2, 64, 32, seed=41)
+    g = torch.Generator().manual_seed(42)
+    feat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
+    cfeat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
+    omodel.set_input(inp)
+    omodel.synthesize_p(feat)
+    lo, ro = omodel.get_loss_G(need_cm=True, cluster_features=cfeat)
+    model.set_input(inp)
+    model.synthesize_p(feat.to(dev))
+    lg, rg = model.get_loss_G(need_cm=True, cluster_features=cfeat.to(dev))
+    assert abs(float(lg) - float(lo)) <= 1e-3 * abs(float(lo)), (float(lg), float(lo))
+    assert tuple(rg.shape) == (2,)
+    _check(rg, ro, 1e-3, "loss_rec per sample")
+    w = torch.tensor([0.3, 1.7])
+    omodel.optimizer_G.zero_grad()
+    (lo + (ro * w).sum()).backward()
+    model.optimizer_G.zero_grad()
+    from rg_hip.tape import backward as rg_backward
+    rg_backward(lg + (rg * w.to(dev)).sum())
+    _check_grads(model.net_G.module, omodel.net_G, 5e-3, "get_loss_G(need_cm) grads", tol_tensor=5e-2)
+    with pytest.raises(TypeError):
+        model.get_loss_G(need_cm=True)
+
+
 def test_joint_step_4a(dev):
     """BASELINE config 4a — the joint ReID + GAN step as committed (trainers_b.py:617-774): ResNet-50 cluster-contrast
     encoder (GeM) -> PoseGenerator1 from the detached feature map -> lsgan / L1 generator loss + cluster-contrast loss ->
