@@ -379,6 +379,9 @@ int rg_l1_bwd(const float* a, const float* b, const int64_t* row_labels, const f
 int rg_l1_rows_fwd(const float* a, const float* b, float* out, int rows, int64_t inner, rg_stream_t stream);
 int rg_l1_rows_bwd(const float* a, const float* b, const float* grad_rows, float* da, float* db, int rows, int64_t inner,
                    rg_stream_t stream);
+/* out[r] = mean_i (x[r][i] - c)^2: GANLoss('lsgan')(D(fake), label)'s map averaged per sample, AE_model.py:378-384 get_L1_loss(with_dis) */
+int rg_mse_const_rows_fwd(const float* x, float c, float* out, int rows, int64_t inner, rg_stream_t stream);
+int rg_mse_const_rows_bwd(const float* x, float c, const float* grad_rows, float* dx, int rows, int64_t inner, rg_stream_t stream);
 /* F.cross_entropy(scale*logits, labels, reduction='none'), FD/fdgan/model.py:189, CC/.../cm.py:134-135 */
 int rg_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_rows, float* lse, int B, int K,
                       float scale, rg_stream_t stream);

@@ -491,6 +491,16 @@ class OAEModel(object):
         self.loss_G = app.mean() + ad.mean()
         return self.loss_G
 
+    def get_L1_loss(self, with_dis=False):
+        """:378-390: per-sample mean |fake - source|; with_dis: lambda_rec * that + lambda_g * per-sample mean of the lsgan map"""
+        rec = (self.fake_image - self.source_image).abs().flatten(1).mean(dim=-1)
+        if not with_dis:
+            return rec
+        for p in self.net_D.parameters():
+            p.requires_grad = False
+        dis = o_lsgan(self.net_D(self.fake_image), True, False).flatten(1).mean(dim=-1)
+        return rec * self.lambda_rec + dis * self.lambda_g
+
     def optimize_generated(self):
         """D update then G update on an already synthesised fake (:403-410)."""
         self.optimizer_D.zero_grad()

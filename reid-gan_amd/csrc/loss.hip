@@ -175,6 +175,28 @@ __global__ void l1_rows_bwd_kernel(const float* __restrict__ a, const float* __r
     }
 }
 
+// out[r] = mean_i (x[r][i] - c)^2 (the lsgan map of GANLoss against a constant label, per sample) and its backward
+__global__ __launch_bounds__(256) void mse_const_rows_fwd_kernel(const float* __restrict__ x, float c, float* __restrict__ out,
+                                                                 int64_t inner) {
+    __shared__ float red[16];
+    const float* xr = x + (int64_t)blockIdx.x * inner;
+    float s = 0.f;
+#pragma unroll 4
+    for (int64_t i = threadIdx.x; i < inner; i += 256) {
+        const float d = xr[i] - c;
+        s += d * d;
+    }
+    s = rg_block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s / (float)inner;
+}
+
+__global__ void mse_const_rows_bwd_kernel(const float* __restrict__ x, float c, const float* __restrict__ g, float* __restrict__ dx,
+                                          int64_t n, int64_t inner) {
+    const float k = 2.f / (float)inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dx[i] = (x[i] - c) * (g[i / inner] * k);
+}
+
 // per-row cross entropy of scale*logits; one workgroup per row; also stores logsumexp for the backward
 __global__ __launch_bounds__(256) void softmax_ce_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels,
                                                              float* __restrict__ loss, float* __restrict__ lse, int K,
@@ -370,6 +392,22 @@ extern "C" int rg_l1_rows_bwd(const float* a, const float* b, const float* grad_
     rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 16.0 * n);
     hipLaunchKernelGGL(l1_rows_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, grad_rows, da, db, n, inner);
     return rg::check_launch("rg_l1_rows_bwd");
+}
+
+extern "C" int rg_mse_const_rows_fwd(const float* x, float c, float* out, int rows, int64_t inner, hipStream_t stream) {
+    RG_REQUIRE(x && out && rows > 0 && inner > 0, "rg_mse_const_rows_fwd: bad arguments");
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 4.0 * rows * (double)inner);
+    hipLaunchKernelGGL(mse_const_rows_fwd_kernel, dim3(rows), dim3(256), 0, stream, x, c, out, inner);
+    return rg::check_launch("rg_mse_const_rows_fwd");
+}
+
+extern "C" int rg_mse_const_rows_bwd(const float* x, float c, const float* grad_rows, float* dx, int rows, int64_t inner,
+                                     hipStream_t stream) {
+    RG_REQUIRE(x && grad_rows && dx && rows > 0 && inner > 0, "rg_mse_const_rows_bwd: bad arguments");
+    const int64_t n = (int64_t)rows * inner;
+    rg::ProfScope prof(rg::FAM_LOSS, stream, 0.0, 8.0 * n);
+    hipLaunchKernelGGL(mse_const_rows_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, c, grad_rows, dx, n, inner);
+    return rg::check_launch("rg_mse_const_rows_bwd");
 }
 
 extern "C" int rg_softmax_ce_fwd(const float* logits, const int64_t* labels, float* loss_rows, float* lse, int B, int K,

@@ -29,6 +29,15 @@ from . import base_function, external_function, networks
 from .base_model import BaseModel
 
 
+def _weighted_rows(terms):
+    """sum_i w_i * v_i for per-sample vectors (two axpby launches at most; autograd through torch's own add / mul on [B] vectors)"""
+    out = None
+    for v, w in terms:
+        t = v * float(w)
+        out = t if out is None else out + t
+    return out
+
+
 def _weighted(terms):
     """sum_i w_i * loss_i of 0-dim device losses in one kernel (keeps the autograd graph)."""
     vals = torch.stack([t for t, _ in terms])
@@ -247,19 +256,29 @@ class AEModel(BaseModel):
         self.loss_G = self.loss_G.detach()
 
     def get_loss_G(self, group_size=None, cf_temp=0.2, need_cm=True, cluster_features=None):
+        if need_cm and cluster_features is None:
+            raise TypeError("get_loss_G(need_cm=True) needs cluster_features (the reference fails inside net_G without them)")
         self.loss_G = self._loss_G_mean()
         if need_cm:
             # synthesize from the cluster features and report its per-sample reconstruction error (AE_model.py:361-372); the
             # generator objective itself is the same mean as without it
-            if cluster_features is None:
-                raise TypeError("get_loss_G(need_cm=True) needs cluster_features (the reference fails inside net_G without them)")
             cluster_image = self.net_G(cluster_features, self.source_pose)
             loss_rec = RF.l1_loss_rows(cluster_image, self.source_image)
             return self.loss_G, loss_rec
         return self.loss_G
 
     def get_L1_loss(self, with_dis=False):
-        raise NotImplementedError("per-sample L1 maps are used only by commented-out trainer variants")
+        """per-sample losses of the current fake (AE_model.py:378-390): mean |fake - source| per sample, or with the discriminator
+        lambda_rec * that + lambda_g * the per-sample mean of the GAN map"""
+        if not with_dis:
+            return RF.l1_loss_rows(self.fake_image, self.source_image)
+        if self.opt.gan_mode != 'lsgan':
+            raise NotImplementedError("get_L1_loss(with_dis=True) per-sample GAN term: only --gan_mode lsgan (the default) is built")
+        base_function._unfreeze(self.net_D)
+        base_function._freeze(self.net_D)                     # backward_G_basic(use_d=True) order, AE_model.py:323-326
+        loss_rec = RF.l1_loss_rows(self.fake_image, self.source_image)
+        loss_dis = RF.mse_const_rows(self.net_D(self.fake_image), self.GANloss.label(True))
+        return _weighted_rows([(loss_rec, self.opt.lambda_rec), (loss_dis, self.opt.lambda_g)])
 
     # ---- stand-alone GAN step (AE_model.py:392-410) ------------------------------------------------------
     def optimize_parameters(self):

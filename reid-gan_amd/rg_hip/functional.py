@@ -103,6 +103,24 @@ def l1_loss_rows(a, b):
     return _L1Rows.apply(a, b)
 
 
+class _MSEConstRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target):
+        ctx.save_for_backward(x)
+        ctx.target = float(target)
+        return ops.mse_const_rows_fwd(x, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.mse_const_rows_bwd(x, ctx.target, g.contiguous()), None
+
+
+def mse_const_rows(x, target):
+    """((x - target) ** 2).flatten(1).mean(-1)"""
+    return _MSEConstRows.apply(x, target)
+
+
 class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, scale):

@@ -1056,6 +1056,22 @@ def l1_rows_bwd(a, b, grad_rows, need_a=True, need_b=True):
     return da, db
 
 
+def mse_const_rows_fwd(x, c):
+    x = _chk(x, "x")
+    rows = x.shape[0]
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib.rg_mse_const_rows_fwd(_p(x), float(c), _p(out), rows, x.numel() // rows, _stream())
+    return out
+
+
+def mse_const_rows_bwd(x, c, grad_rows):
+    x, grad_rows = _chk(x, "x"), _chk(grad_rows, "grad_rows")
+    rows = x.shape[0]
+    dx = torch.empty_like(x)
+    lib.rg_mse_const_rows_bwd(_p(x), float(c), _p(grad_rows), _p(dx), rows, x.numel() // rows, _stream())
+    return dx
+
+
 def softmax_ce_fwd(logits, labels, scale=1.0):
     logits = _chk(logits, "logits")
     labels = _chk(labels, "labels", torch.int64)

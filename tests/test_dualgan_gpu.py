@@ -223,6 +223,17 @@ def test_aemodel_get_loss_G_with_cluster_reconstruction(dev):
     _check_grads(model.net_G.module, omodel.net_G, 5e-3, "get_loss_G(need_cm) grads", tol_tensor=5e-2)
     with pytest.raises(TypeError):
         model.get_loss_G(need_cm=True)
+    # get_L1_loss (AE_model.py:378-390): per-sample reconstruction error, alone and with the per-sample discriminator term
+    omodel.synthesize_p(feat)
+    model.synthesize_p(feat.to(dev))
+    _check(model.get_L1_loss(), omodel.get_L1_loss(), 1e-3, "get_L1_loss")
+    lo, lg = omodel.get_L1_loss(with_dis=True), model.get_L1_loss(with_dis=True)
+    _check(lg, lo, 1e-3, "get_L1_loss(with_dis)")
+    omodel.optimizer_G.zero_grad()
+    (lo * w).sum().backward()
+    model.optimizer_G.zero_grad()
+    rg_backward((lg * w.to(dev)).sum())
+    _check_grads(model.net_G.module, omodel.net_G, 5e-3, "get_L1_loss(with_dis) grads", tol_tensor=5e-2)
 
 
 def test_joint_step_4a(dev):

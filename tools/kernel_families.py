@@ -45,7 +45,7 @@ FAMILY = {
     "pair_cat_kernel": "eltwise", "sub_square_bwd_kernel": "eltwise", "sub_square_fwd_kernel": "eltwise",
     # loss.hip
     "affine_relu_mean_bwd_kernel": "loss", "affine_relu_mean_partial_kernel": "loss", "bce_bwd_kernel": "loss",
-    "bce_partial_kernel": "loss", "finalize_sum_kernel": "loss", "grad_penalty_rows_kernel": "loss", "l1_bwd_kernel": "loss", "l1_rows_fwd_kernel": "loss", "l1_rows_bwd_kernel": "loss",
+    "bce_partial_kernel": "loss", "finalize_sum_kernel": "loss", "grad_penalty_rows_kernel": "loss", "l1_bwd_kernel": "loss", "l1_rows_fwd_kernel": "loss", "mse_const_rows_fwd_kernel": "loss", "mse_const_rows_bwd_kernel": "loss", "l1_rows_bwd_kernel": "loss",
     "l1_finalize_kernel": "loss", "l1_partial_kernel": "loss", "mse_const_bwd_kernel": "loss",
     "mse_const_partial_kernel": "loss", "softmax_ce_bwd_kernel": "loss", "softmax_ce_fwd_kernel": "loss",
     "wsum_bwd_kernel": "loss", "wsum_kernel": "loss",
