@@ -451,6 +451,36 @@ def o_my_transform(x, size=(256, 128), mean=(0.485, 0.456, 0.406), std=(0.229, 0
     return y
 
 
+class OResBlockSN(nn.Module):
+    """base_function.py:193-233 as Resize_ReID builds it (networks.py:152-157): BatchNorm, ReLU, spectral-normed convolutions"""
+
+    def __init__(self, cin, cout, norm='batch', sn=True):
+        super(OResBlockSN, self).__init__()
+        self.conv1 = _sn(nn.Conv2d(cin, cout, 3, 1, 1), sn)
+        self.conv2 = _sn(nn.Conv2d(cout, cout, 3, 1, 1), sn)
+        self.bypass = _sn(nn.Conv2d(cin, cout, 1), sn)
+        self.model = nn.Sequential(_norm2d(norm, cin), nn.ReLU(), self.conv1, _norm2d(norm, cout), nn.ReLU(), self.conv2)
+        self.shortcut = nn.Sequential(self.bypass)
+
+    def forward(self, x):
+        return self.model(x) + self.shortcut(x)
+
+
+class OResize_ReID(nn.Module):
+    """networks.py:140-162: `my_resize` (bicubic, diff_augs.py:6-7) of the synthesised 128x64 image to 256x128, three residual blocks
+    3 -> 64 -> 64 -> 3 added back onto the resized image"""
+
+    def __init__(self, image_nc=3, ngf=64):
+        super(OResize_ReID, self).__init__()
+        self.resblock1 = OResBlockSN(image_nc, ngf)
+        self.resblock2 = OResBlockSN(ngf, ngf)
+        self.resblock3 = OResBlockSN(ngf, image_nc)
+
+    def forward(self, inputs):
+        x = o_my_transform(inputs, (256, 128), normalize=False)
+        return x + self.resblock3(self.resblock2(self.resblock1(x)))
+
+
 class OAEModel(object):
     """AEModel with model_gen='Pose', lsgan, no VGG loss (CC/dual_gan/models/AE_model.py:58-160, 212-214, 294-376)."""
 

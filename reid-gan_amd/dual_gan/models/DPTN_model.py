@@ -92,9 +92,12 @@ class DPTNModel(BaseModel):
                                        norm=opt.norm, activation='LeakyReLU', use_spect=opt.use_spect_g,
                                        use_coord=opt.use_coord, output_nc=3, num_blocks=3, affine=True, nhead=opt.nhead,
                                        num_CABs=opt.num_CABs, num_TTBs=opt.num_TTBs)
-        self.use_adp = getattr(opt, 'use_adp', False)
+        # --use_adp (DPTN_model.py:56-59): the adaptor from synthesised 128x64 images to 256x128 ReID inputs; synthesize() /
+        # synthesize_pair() pass their images through it, and without --gan_train it is the only network that trains (:91-105)
+        self.use_adp = bool(getattr(opt, 'use_adp', False))
         if self.use_adp:
-            raise NotImplementedError("--use_adp: net_A (Resize_ReID) is not on the training step and not rebuilt")
+            self.model_names = ['G', 'A']
+            self.net_A = networks.Resize_ReID(image_nc=opt.image_nc).to(self.device)
 
         if self.gan_train:
             self.model_names = ['G', 'D']
@@ -152,6 +155,15 @@ class DPTNModel(BaseModel):
                         st.roll()
                     return out
                 self.optimizer_G.step = step_and_roll
+        elif self.use_adp:
+            print("use adaptor")
+            self.net_G.eval()                                   # only the adaptor trains
+            self.old_lr = opt.gan_lr
+            self.optimizer_A = roptim.Adam(itertools.chain(filter(lambda p: p.requires_grad, self.net_A.parameters())),
+                                           lr=opt.gan_lr, betas=(opt.beta1, 0.999))
+            self.schedulers = base_function.get_scheduler(self.optimizer_A, opt)
+            self._red_A = GradReducer(self.optimizer_A, modules=[self.net_A])
+            _wrap_step(self.optimizer_A, self._red_A)
         else:
             self.net_G.eval()
 
@@ -183,11 +195,17 @@ class DPTNModel(BaseModel):
 
     def synthesize(self, is_tain=False):
         self.fake_image_t, self.fake_image_s = self.net_G(self.source_image, self.source_pose, self.target_pose, is_tain)
+        if self.use_adp:
+            # (with is_tain False the generator returns None for the source branch; the reference would fail inside my_resize)
+            self.fake_image_t = self.net_A(self.fake_image_t)
+            self.fake_image_s = self.net_A(self.fake_image_s) if self.fake_image_s is not None else None
         return self.fake_image_t, self.fake_image_s
 
     def synthesize_pair(self):
         self.fake_image_n, _ = self.net_G(torch.flip(self.source_image, dims=[0]).contiguous(),
                                           torch.flip(self.source_pose, dims=[0]).contiguous(), self.target_pose, False)
+        if self.use_adp:
+            self.fake_image_n = self.net_A(self.fake_image_n)
         return self.fake_image_n
 
     # ---- discriminator update (DPTN_model.py:159-182) --------------------------------------------------------

@@ -94,3 +94,13 @@ def decgen_case():
     g = torch.Generator().manual_seed(66)
     feat = torch.nn.functional.normalize(torch.randn(2, 2048, 8, 4, generator=g).abs(), dim=1)
     return net, feat
+
+
+def resize_reid_case():
+    """--use_adp: the adaptor from synthesised 128x64 images to ReID inputs"""
+    torch.manual_seed(50)
+    net = D.o_init_weights(D.OResize_ReID(3, 64))
+    _perturb(net, 51, 0.02)
+    net.train()
+    g = torch.Generator().manual_seed(52)
+    return net, torch.tanh(torch.randn(2, 3, 32, 16, generator=g))

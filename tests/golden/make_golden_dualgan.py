@@ -49,7 +49,10 @@ def import_reference():
     for name in ("clustercontrast", "clustercontrast.utils", "clustercontrast.utils.data"):
         sys.modules.setdefault(name, types.ModuleType(name))
     shell = types.ModuleType("clustercontrast.utils.data.diff_augs")
-    shell.my_resize = shell.my_transform = shell.my_normalize = None
+    shell.my_transform = shell.my_normalize = None
+    # Resize_ReID (networks.py:160) calls my_resize: torchvision's tensor resize is F.interpolate(bicubic) — the anchor the
+    # bicubic fixture already uses; everything after it in that module is the reference's own code
+    shell.my_resize = lambda X, size=(256, 128): torch.nn.functional.interpolate(X, size=size, mode='bicubic', align_corners=False)
     sys.modules["clustercontrast.utils.data.diff_augs"] = shell
     pkg = types.ModuleType("dual_gan")
     pkg.__path__ = [os.path.join(CC, "dual_gan")]
@@ -141,6 +144,26 @@ def main():
         for k in gsel:
             check(po[k].grad, pr[k].grad, tag + " grad " + k, 2e-4)
             out[tag + "_g_" + k], _ = sub(pr[k].grad)
+
+    print("Resize_ReID (--use_adp)")
+    on, x = C.resize_reid_case()
+    rn = ref_net.Resize_ReID(image_nc=3)
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    xo, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yo, yr = on(xo), rn(xr)
+    check(yo, yr, "resize_reid_fwd")
+    g = torch.Generator().manual_seed(8)
+    dy = torch.randn(yr.shape, generator=g)
+    yo.backward(dy)
+    yr.backward(dy)
+    check(xo.grad, xr.grad, "resize_reid_dx", 1e-4)
+    out["resize_reid_fwd"], out["resize_reid_fwd_stats"] = sub(yr)
+    out["resize_reid_dx"], out["resize_reid_dx_stats"] = sub(xr.grad)
+    pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+    for k in ["resblock1.conv1.weight_orig", "resblock2.bypass.weight_orig", "resblock3.conv2.bias", "resblock2.model.0.weight"]:
+        check(po[k].grad, pr[k].grad, "resize_reid grad " + k, 2e-4)
+        out["resize_reid_g_" + k], _ = sub(pr[k].grad)
 
     print("DPTNGenerator")
     on, (xs, ps, pt) = C.dptn_case()

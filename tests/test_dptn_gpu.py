@@ -303,3 +303,82 @@ def test_dptn_steps_are_bit_identical_between_runs(dev, conv_dtype):
     assert l1 == l2
     assert torch.equal(f1, f2)
     assert torch.equal(p1, p2)
+
+
+def test_use_adp_adaptor_and_adaptor_only_training(dev):
+    """--use_adp (DPTN_model.py:56-59, 91-105, 142-154): Resize_ReID against the oracle (== reference, golden `resize_reid_*`), then a
+    DPTNModel without --gan_train whose synthesize() / synthesize_pair() pass through the adaptor and whose only optimizer is the
+    adaptor's."""
+    import copy
+    from dual_gan.models import networks as N
+    from dual_gan.models.models import create_model
+    from oracle import ref_dualgan as D
+    from tests.golden import cases_dualgan as CD
+    from tests.test_modules_gpu import _check_grads
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_dualgan.npz"))
+    on, x = CD.resize_reid_case()
+    rg = N.Resize_ReID(image_nc=3)
+    rg.load_state_dict(on.state_dict())
+    rg = rg.to(dev).train()
+    o64 = copy.deepcopy(on).double()            # gradients judged against fp64 (train-mode BatchNorm over two samples, ReLU kinks)
+    xo, xd = x.double().requires_grad_(True), x.to(dev).requires_grad_(True)
+    yo, y = o64(xo), rg(xd)
+    _check(y, yo, 1e-3, "Resize_ReID fwd")
+    ref = gold["resize_reid_fwd"]
+    got = np.asarray(sub(y.detach().cpu())[0], dtype=np.float64).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+    g = torch.Generator().manual_seed(8)
+    dy = torch.randn(yo.shape, generator=g)
+    yo.backward(dy.double())
+    y.backward(dy.to(dev))
+    _check_l2(xd.grad, xo.grad, 5e-3, "Resize_ReID dx")
+    _check_grads(rg, o64, 5e-3, "Resize_ReID grads", tol_tensor=5e-2)
+    # the model: no --gan_train, --use_adp
+    opt = _opt("hinge")
+    opt.gan_train, opt.use_adp = False, True
+    m = create_model(opt)
+    assert m.model_names == ['G', 'A'] and not hasattr(m, "optimizer_G") and hasattr(m, "optimizer_A")
+    om = C.model("hinge", False)
+    m.net_G.module.load_state_dict(om.net_G.state_dict())
+    oa, _ = CD.resize_reid_case()
+    m.net_A.load_state_dict(oa.state_dict())
+    assert not m.net_G.training                 # only the adaptor trains
+    og = om.net_G.eval()
+    oa.train()
+    d = C.inputs()
+    m.set_input({k: v.to(dev) for k, v in d.items()})
+    ft, fs = m.synthesize(True)
+    with torch.no_grad():
+        rt, rs = og(d['Xs'], d['Ps'], d['Pt'], True)
+    ot, os_ = oa(rt), oa(rs)
+    assert tuple(ft.shape) == (rt.shape[0], 3, 256, 128)
+    _check(ft, ot, 1e-3, "synthesize(use_adp) target branch")
+    _check(fs, os_, 1e-3, "synthesize(use_adp) source branch")
+    fn = m.synthesize_pair()
+    with torch.no_grad():
+        rn, _ = og(torch.flip(d['Xs'], dims=[0]), torch.flip(d['Ps'], dims=[0]), d['Pt'], False)
+    _check(fn, oa(rn), 1e-3, "synthesize_pair(use_adp)")          # third training forward of the adaptor on both sides
+    # one adaptor-only update on a surrogate loss
+    w = torch.randn(ot.shape, generator=g)
+    opt_o = torch.optim.Adam(oa.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    opt_o.zero_grad()
+    oa2_t = oa(rt)                              # forwards four and five, in the model's order (target branch, then source branch)
+    oa(rs)
+    (oa2_t * w).mean().backward()
+    opt_o.step()
+    m.optimizer_A.zero_grad()
+    ft2, _ = m.synthesize(True)
+    from rg_hip.tape import backward as rg_backward
+    rg_backward(RF_mean(ft2, w.to(dev)))
+    m.optimizer_A.step()
+    po = dict(oa.named_parameters())
+    moved = 0.0
+    for n, p in m.net_A.named_parameters():
+        assert (p.detach().cpu() - po[n].detach()).abs().max().item() <= 2.5 * 2e-4 + 1e-6, n
+        moved = max(moved, (p.detach().cpu() - dict(CD.resize_reid_case()[0].named_parameters())[n]).abs().max().item())
+    assert moved >= 1e-4                        # the adaptor really stepped
+
+
+def RF_mean(x, w):
+    """(x * w).mean() through torch ops (test-side loss)"""
+    return (x * w).mean()

@@ -112,6 +112,23 @@ def test_dec_generators():
                 _cmp(sub(params[key[len(pre):]].grad)[0], key, 2e-4)
 
 
+def test_resize_reid_adaptor():
+    net, x = C.resize_reid_case()
+    x = x.clone().requires_grad_(True)
+    y = net(x)
+    assert tuple(y.shape) == (2, 3, 256, 128)
+    s, st = sub(y)
+    _cmp(s, "resize_reid_fwd")
+    _cmp(st, "resize_reid_fwd_stats")
+    g = torch.Generator().manual_seed(8)
+    y.backward(torch.randn(y.shape, generator=g))
+    _cmp(sub(x.grad)[0], "resize_reid_dx", 1e-4)
+    params = dict(net.named_parameters())
+    for key in GOLD.files:
+        if key.startswith("resize_reid_g_"):
+            _cmp(sub(params[key[len("resize_reid_g_"):]].grad)[0], key, 2e-4)
+
+
 def test_dptn_generator():
     net, (xs, ps, pt) = C.dptn_case()
     t, s_ = net(xs, ps, pt)
