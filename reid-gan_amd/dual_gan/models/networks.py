@@ -40,8 +40,12 @@ def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='
         raise NotImplementedError("generator 'PoseAE' fails on its first forward in the reference (networks.py:811-813); "
                                   "it is not built on the HIP path")
     elif opt.model_gen == 'FD':
-        raise NotImplementedError("generator 'FD' (FDGenerator under the dual_gan options) is not built on the HIP path; the "
-                                  "FD-GAN generator of the joint step is fdgan.model / 'Pose'")
+        # define_G builds FDGenerator(..., noise_nc=512, fuse_mode='add') (networks.py:23-24), whose forward needs (reid_feature,
+        # noise); every caller in the reference passes ONE argument (AE_model.py:205-210 net_G(source_image) / net_G(features)), so
+        # the first forward dies on `noise.view` of None (networks.py:526-527): no runnable behaviour to reproduce.  The FD-GAN
+        # generator of the joint step is fdgan.networks.CustomPoseGenerator (fdgan.adaptor / config 4b).
+        raise NotImplementedError("generator 'FD' fails on its first forward in the reference (FDGenerator 'add' mode called without "
+                                  "noise, networks.py:526-527 via AE_model.py:205-210); it is not built on the HIP path")
     else:
         raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
     return init_net(netG, opt.init_type)
