@@ -1434,7 +1434,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const ThinP t) {
 // Weight gradient of 3x3 / stride 1 / pad <= 1 layers with Q % 4 == 0 (the Output blocks: 64 -> 3 on a full-resolution map): four
 // output pixels of a row per thread.  Their six input columns per filter row are one 16-byte load plus the two neighbours — 9 load
 // instructions for four pixels instead of 36 (206 -> 164 us at 128 x 64 x 128 x 64; the same idea made the forward kernel slower).
-template <int KO>
 __device__ __forceinline__ void thin_px4_offsets(const ThinP& t, int pix, unsigned (&ol)[3], unsigned (&om)[3], unsigned (&orr)[3],
                                                  int& img, int& pq) {
     const int PQ = t.P * t.Q;
@@ -1473,7 +1472,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_k1_px4_kernel(const ThinP t) {
     for (int pix = beg + threadIdx.x * 4; pix < end; pix += 1024) {
         unsigned ol[3], om[3], orr[3];
         int img, pq;
-        thin_px4_offsets<KO>(t, pix, ol, om, orr, img, pq);
+        thin_px4_offsets(t, pix, ol, om, orr, img, pq);
         float g[KO][4];
 #pragma unroll
         for (int k = 0; k < KO; ++k) {
@@ -2072,8 +2071,6 @@ static unsigned finish_grid(int64_t n) {
     if (g > 4096) g = 4096;
     return (unsigned)(g < 1 ? 1 : g);
 }
-
-static void launch_reduce(hipStream_t stream, const float* ws, float* out, int64_t n, int splits, int rsc, int C, int RS);
 
 // development switch: RG_SPLITK_VEC=0 keeps the scalar finishing / reduction kernels
 static bool splitk_vec() {

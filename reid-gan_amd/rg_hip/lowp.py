@@ -203,10 +203,6 @@ class F8Layer(object):
         self.sx.prepare(x)
         return quantize_dual(x, self.sx, True, want_chwn)
 
-    def quant_grad_both(self, dy, want_nhwc, want_chwn):
-        self.sdy.prepare(dy)
-        return quantize_dual(dy, self.sdy, want_nhwc, want_chwn)
-
     def quant_grad_fused(self, dy, y, act, slope, want_nhwc, want_chwn, want_sum):
         """(dyq, dyq_t, bias gradient or None) of g = dy * act'(y).  With a calibrated delayed scale everything is one launch
         (+ the column sum of the tile partials for the bias); a scale that has to be measured first needs g itself, so that case
