@@ -156,50 +156,61 @@ __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __res
 // The same normalisation along the CHANNEL axis of an [N][C][HW] map (F.normalize(x, dim=1) of a feature map: unit norm over the
 // channels at every pixel) without the two permuted copies a row view would need.  Workgroup = 64 pixels x 4 channel groups of one
 // image: lanes run along the pixels (coalesced rows of every channel), group g owns channels g, g + 4, ...; eight loads in flight.
+// PX = 16 pixels x 16 channel groups when the 64-pixel form would leave most of the chip idle (a [32, 2048, 16 x 8] map is 64
+// workgroups of 64 pixels: 102 us for 100 MB; 256 workgroups of 16 pixels run at the memory rate).
+template <int PX>
 __global__ __launch_bounds__(256) void l2norm_channels_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   float* __restrict__ norm, int C, int HW, float eps) {
-    __shared__ float red[4][64];
-    const int lp = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int px = blockIdx.x * 64 + lp, n = blockIdx.y;
+    constexpr int G = 256 / PX;
+    __shared__ float red[G][PX];
+    const int lp = threadIdx.x % PX, g = threadIdx.x / PX;
+    const int px = blockIdx.x * PX + lp, n = blockIdx.y;
     const bool ok = px < HW;
     const float* xb = x + (int64_t)n * C * HW + (ok ? px : 0);
     float s = 0.f;
 #pragma unroll 8
-    for (int c = g; c < C; c += 4) {
+    for (int c = g; c < C; c += G) {
         const float v = ok ? xb[(int64_t)c * HW] : 0.f;
         s += v * v;
     }
     red[g][lp] = s;
     __syncthreads();
-    const float nr = sqrtf((red[0][lp] + red[1][lp]) + (red[2][lp] + red[3][lp]));
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) tot += red[i][lp];
+    const float nr = sqrtf(tot);
     const float inv = 1.f / fmaxf(nr, eps);
     if (!ok) return;
     float* yb = y + (int64_t)n * C * HW + px;
 #pragma unroll 8
-    for (int c = g; c < C; c += 4) yb[(int64_t)c * HW] = xb[(int64_t)c * HW] * inv;
+    for (int c = g; c < C; c += G) yb[(int64_t)c * HW] = xb[(int64_t)c * HW] * inv;
     if (norm && g == 0) norm[(int64_t)n * HW + px] = nr;
 }
 
+template <int PX>
 __global__ __launch_bounds__(256) void l2norm_channels_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                                   const float* __restrict__ norm, float* __restrict__ dx, int C,
                                                                   int HW, float eps) {
-    __shared__ float red[4][64];
-    const int lp = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int px = blockIdx.x * 64 + lp, n = blockIdx.y;
+    constexpr int G = 256 / PX;
+    __shared__ float red[G][PX];
+    const int lp = threadIdx.x % PX, g = threadIdx.x / PX;
+    const int px = blockIdx.x * PX + lp, n = blockIdx.y;
     const bool ok = px < HW;
     const int64_t base = (int64_t)n * C * HW + (ok ? px : 0);
     float s = 0.f;
 #pragma unroll 8
-    for (int c = g; c < C; c += 4) s += ok ? y[base + (int64_t)c * HW] * dy[base + (int64_t)c * HW] : 0.f;
+    for (int c = g; c < C; c += G) s += ok ? y[base + (int64_t)c * HW] * dy[base + (int64_t)c * HW] : 0.f;
     red[g][lp] = s;
     __syncthreads();
     if (!ok) return;
-    const float dot = (red[0][lp] + red[1][lp]) + (red[2][lp] + red[3][lp]);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) dot += red[i][lp];
     const float nr = norm[(int64_t)n * HW + px];
     const float inv = 1.f / fmaxf(nr, eps);
     const float k = nr > eps ? dot : 0.f;
 #pragma unroll 8
-    for (int c = g; c < C; c += 4) dx[base + (int64_t)c * HW] = (dy[base + (int64_t)c * HW] - y[base + (int64_t)c * HW] * k) * inv;
+    for (int c = g; c < C; c += G) dx[base + (int64_t)c * HW] = (dy[base + (int64_t)c * HW] - y[base + (int64_t)c * HW] * k) * inv;
 }
 
 // channel-block copy between NCHW tensors: dst[n][dc0 + c][hw] = src[n][sc0 + c][hw], c < Cc
@@ -339,7 +350,10 @@ extern "C" int rg_l2norm_rows_bwd(const float* y, const float* dy, const float* 
 extern "C" int rg_l2norm_channels_fwd(const float* x, float* y, float* norm, int N, int C, int HW, float eps, hipStream_t stream) {
     RG_REQUIRE(x && y && N > 0 && C > 0 && HW > 0 && N <= 65535, "rg_l2norm_channels_fwd: bad arguments");
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 8.0 * N * (double)C * HW);
-    hipLaunchKernelGGL(l2norm_channels_fwd_kernel, dim3(rg::cdiv(HW, 64), N), dim3(256), 0, stream, x, y, norm, C, HW, eps);
+    if ((int64_t)rg::cdiv(HW, 64) * N >= 1024)
+        hipLaunchKernelGGL(l2norm_channels_fwd_kernel<64>, dim3(rg::cdiv(HW, 64), N), dim3(256), 0, stream, x, y, norm, C, HW, eps);
+    else
+        hipLaunchKernelGGL(l2norm_channels_fwd_kernel<16>, dim3(rg::cdiv(HW, 16), N), dim3(256), 0, stream, x, y, norm, C, HW, eps);
     return rg::check_launch("rg_l2norm_channels_fwd");
 }
 
@@ -347,7 +361,10 @@ extern "C" int rg_l2norm_channels_bwd(const float* y, const float* dy, const flo
                                       hipStream_t stream) {
     RG_REQUIRE(y && dy && norm && dx && N > 0 && C > 0 && HW > 0 && N <= 65535, "rg_l2norm_channels_bwd: bad arguments");
     rg::ProfScope prof(rg::FAM_ELTWISE, stream, 0.0, 12.0 * N * (double)C * HW);
-    hipLaunchKernelGGL(l2norm_channels_bwd_kernel, dim3(rg::cdiv(HW, 64), N), dim3(256), 0, stream, y, dy, norm, dx, C, HW, eps);
+    if ((int64_t)rg::cdiv(HW, 64) * N >= 1024)
+        hipLaunchKernelGGL(l2norm_channels_bwd_kernel<64>, dim3(rg::cdiv(HW, 64), N), dim3(256), 0, stream, y, dy, norm, dx, C, HW, eps);
+    else
+        hipLaunchKernelGGL(l2norm_channels_bwd_kernel<16>, dim3(rg::cdiv(HW, 16), N), dim3(256), 0, stream, y, dy, norm, dx, C, HW, eps);
     return rg::check_launch("rg_l2norm_channels_bwd");
 }
 
