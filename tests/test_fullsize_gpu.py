@@ -13,6 +13,9 @@ parity tests proper run small; these cover what only shows at full size: the til
 * the fp8 convolution family at BASELINE config 5's sizes (128 samples = 2 branches x 64 crops of 128x64): the three GEMMs equal the
   fp32 MFMA convolution of the DEQUANTISED operands (fp8 x fp8 products are exact in fp32, so only the accumulation order differs),
   both quantiser layouts hold the same bytes, power-of-two input scaling moves only the scale, two runs are bit-identical.
+* the pass-fusing kernels of round 3 at config-5 / config-3 sizes: the gradient quantiser with the activation backward and the bias sums
+  folded in writes the bytes of the unfused sequence; reflection pad with the activation folded in equals torch's pad of the activation;
+  channel-axis L2 normalisation equals the row kernel on the permuted view; InstanceNorm with the instance in registers equals torch;
 * BASELINE config 1 as stated (the reference's own CPU-runnable case): `extract_cnn_feature` of `create('resnet50',
   cut_at_pooling=True)` in eval mode on 64 crops of 256x128 -> [64, 2048], compared DIRECTLY with the oracle's CPU forward (1e-3).
 """
@@ -293,3 +296,56 @@ def test_config1_eval_features_64_crops_against_the_oracle(dev):
     # each crop's feature is independent of its batch neighbours (frozen statistics): two half batches give the same rows
     half = torch.cat([extract_cnn_feature(r, x[:32]), extract_cnn_feature(r, x[32:])])
     assert (half - got).abs().max().item() <= 1e-5 * got.abs().max().item()
+
+
+def test_round3_pass_fusions_at_full_size(dev):
+    from rg_hip import lowp, ops
+    g = torch.Generator(device=dev).manual_seed(77)
+    # (1) fp8 gradient quantiser, config-5 decoder shape: fused activation backward + bias partial sums == the unfused sequence
+    shape = (128, 64, 64, 32)
+    dy = torch.randn(shape, generator=g, device=dev) * torch.exp(torch.randn(shape, generator=g, device=dev))
+    y = torch.randn(shape, generator=g, device=dev)
+    st = lowp.F8States(dev, capacity=4)
+    st.policy = "jit"
+    s = st.new(lowp.E5M2)
+    st.finalize()
+    gref = ops.act_bwd(dy, y, ops.ACT_LEAKY, 0.1)
+    s.prepare(gref)
+    ua, ub = lowp.quantize_dual(gref, s)
+    fa, fb, part = lowp.quantize_grad_dual(dy, s, True, True, y=y, act=ops.ACT_LEAKY, slope=0.1, want_sum=True)
+    assert torch.equal(fa.buf, ua.buf) and torch.equal(fb.buf, ub.buf)
+    db = ops.rows_sum_pair(part, None, part.shape[0], shape[1])[0]
+    ref = gref.double().sum((0, 2, 3))
+    assert (db.double() - ref).abs().max().item() <= 2e-6 * gref.double().abs().sum((0, 2, 3)).max().item()
+    assert torch.equal(db, ops.rows_sum_pair(part, None, part.shape[0], shape[1])[0])           # fixed summation order
+    del ua, ub, fa, fb, gref
+    # (2) Output block: pad(leaky(x)) and its adjoint on the 64-channel full-resolution map of config 5 (64 crops here)
+    x = torch.randn(64, 64, 128, 64, generator=g, device=dev)
+    yp = ops.reflection_pad2d_fwd(x, 1, ops.ACT_LEAKY, 0.1)
+    assert torch.equal(yp, F.pad(F.leaky_relu(x, 0.1), (1, 1, 1, 1), mode="reflect"))
+    dyp = torch.randn(yp.shape, generator=g, device=dev)
+    dx = ops.reflection_pad2d_bwd(dyp, 1, x, ops.ACT_LEAKY, 0.1)
+    # adjoint identity <pad(act(x)), dyp> versus <act'(x) * pad^T(dyp), x> does not hold for a nonlinearity; check linearity in dyp
+    dx2 = ops.reflection_pad2d_bwd(dyp * 2.0, 1, x, ops.ACT_LEAKY, 0.1)
+    assert torch.equal(dx2, dx * 2.0)
+    lin = ops.reflection_pad2d_bwd(dyp, 1)                       # no activation: <pad(x), dyp> == <x, pad^T(dyp)>
+    yp_lin = ops.reflection_pad2d_fwd(x, 1)
+    lhs = yp_lin.double().mul(dyp.double()).sum().item()
+    rhs = lin.double().mul(x.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * yp_lin.double().abs().mul(dyp.double().abs()).sum().item()
+    del x, yp, dyp, dx, dx2, lin, yp_lin
+    # (3) F.normalize over the channels of the [64, 2048, 16, 8] map (config 3) == the row kernel on the permuted view
+    fmap = torch.randn(64, 2048, 16, 8, generator=g, device=dev)
+    yn, nrm = ops.l2norm_channels_fwd(fmap)
+    rows = fmap.permute(0, 2, 3, 1).reshape(-1, 2048).contiguous()
+    yr, nr = ops.l2norm_rows_fwd(rows)
+    assert (yn.permute(0, 2, 3, 1).reshape(-1, 2048) - yr).abs().max().item() <= 1e-6
+    assert (nrm.reshape(-1) - nr).abs().max().item() <= 1e-4 * nr.max().item()
+    assert (yn.double().pow(2).sum(1) - 1).abs().max().item() <= 1e-5
+    # (4) InstanceNorm with the instance in registers at the DPTN decoder shape
+    xi = torch.randn(128, 64, 64, 32, generator=g, device=dev) * 1.5 + 0.2
+    yi, mean, invstd = ops.instnorm_fwd(xi, None, None, None, 1e-5, ops.ACT_NONE, 0.0)
+    m = xi.double().mean((2, 3))
+    v = xi.double().var((2, 3), unbiased=False)
+    assert (mean.view(128, 64).double() - m).abs().max().item() <= 1e-5
+    assert (yi.double() - (xi.double() - m[..., None, None]) / (v[..., None, None] + 1e-5).sqrt()).abs().max().item() <= 2e-5
