@@ -451,6 +451,48 @@ def o_my_transform(x, size=(256, 128), mean=(0.485, 0.456, 0.406), std=(0.229, 0
     return y
 
 
+class OFDGenerator(nn.Module):
+    """networks.py:449-538 (`--model_gen FD`: fuse_mode='add', noise_nc=512, BatchNorm): W_reid / W_noise -> ReLU -> ConvT(8,4) ->
+    norm -> dropout, four [ReLU, ConvT 4x4/2, norm, dropout] blocks, [ReLU, ConvT 4x4/2, Tanh]"""
+
+    def __init__(self, reid_feature_nc, ngf=64, noise_nc=3, output_nc=3, dropout=0.0, fuse_mode='none'):
+        super(OFDGenerator, self).__init__()
+        self.fuse_mode = fuse_mode
+        if fuse_mode == 'cat':
+            nc = reid_feature_nc + noise_nc
+        elif fuse_mode == 'add':
+            nc = max(reid_feature_nc, noise_nc)
+            self.W_reid = nn.Linear(reid_feature_nc, nc, bias=False)
+            self.W_noise = nn.Linear(noise_nc, nc, bias=False)
+        else:
+            nc = reid_feature_nc
+            self.W_reid = nn.Linear(reid_feature_nc, nc, bias=False)
+
+        def block(cin, cout):
+            return nn.Sequential(nn.ReLU(True), nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False), nn.BatchNorm2d(cout),
+                                 nn.Dropout(dropout))
+        self.de_avg = nn.Sequential(nn.ReLU(True), nn.ConvTranspose2d(nc, ngf * 8, (8, 4), bias=False), nn.BatchNorm2d(ngf * 8),
+                                    nn.Dropout(dropout))
+        self.de_conv5 = block(ngf * 8, ngf * 8)
+        self.de_conv4 = block(ngf * 8, ngf * 4)
+        self.de_conv3 = block(ngf * 4, ngf * 2)
+        self.de_conv2 = block(ngf * 2, ngf)
+        self.de_conv1 = nn.Sequential(nn.ReLU(True), nn.ConvTranspose2d(ngf, output_nc, 4, 2, 1, bias=False), nn.Tanh())
+
+    def forward(self, reid_feature, noise=None):
+        b = reid_feature.shape[0]
+        if self.fuse_mode == 'cat':
+            feature = torch.cat((reid_feature, noise), dim=1)
+        elif self.fuse_mode == 'add':
+            feature = (self.W_reid(reid_feature.view(b, -1)) + self.W_noise(noise.view(b, -1))).view(b, -1, 1, 1)
+        else:
+            feature = self.W_reid(reid_feature.view(b, -1)).view(b, -1, 1, 1)
+        x = self.de_avg(feature)
+        for blk in (self.de_conv5, self.de_conv4, self.de_conv3, self.de_conv2, self.de_conv1):
+            x = blk(x)
+        return x
+
+
 class OResBlockSN(nn.Module):
     """base_function.py:193-233 as Resize_ReID builds it (networks.py:152-157): BatchNorm, ReLU, spectral-normed convolutions"""
 

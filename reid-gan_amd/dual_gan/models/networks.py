@@ -7,10 +7,13 @@ the block programs of base_function.py / PTM.py.
 """
 from __future__ import absolute_import
 
+import functools
+
 import torch
 
 from rg_hip import nn as rnn
 from rg_hip import ops
+from rg_hip.ops import ACT_RELU, ACT_TANH
 from rg_hip.tape import RGModule
 from .base_function import (EncoderBlock, EncoderBlockOptimized, FeatureAdaptBlock1, Output, ResBlock, ResBlockDecoder,
                             ResBlockEncoder, ResBlockEncoderOptimized, SpectralNorm, get_nonlinearity_layer,
@@ -40,12 +43,9 @@ def define_G(opt, image_nc, pose_nc, ngf=64, img_f=1024, encoder_layer=3, norm='
         raise NotImplementedError("generator 'PoseAE' fails on its first forward in the reference (networks.py:811-813); "
                                   "it is not built on the HIP path")
     elif opt.model_gen == 'FD':
-        # define_G builds FDGenerator(..., noise_nc=512, fuse_mode='add') (networks.py:23-24), whose forward needs (reid_feature,
-        # noise); every caller in the reference passes ONE argument (AE_model.py:205-210 net_G(source_image) / net_G(features)), so
-        # the first forward dies on `noise.view` of None (networks.py:526-527): no runnable behaviour to reproduce.  The FD-GAN
-        # generator of the joint step is fdgan.networks.CustomPoseGenerator (fdgan.adaptor / config 4b).
-        raise NotImplementedError("generator 'FD' fails on its first forward in the reference (FDGenerator 'add' mode called without "
-                                  "noise, networks.py:526-527 via AE_model.py:205-210); it is not built on the HIP path")
+        # (every caller in the reference passes ONE argument to net_G — AE_model.py:205-210 — so this 'add'-mode generator dies on
+        # `noise.view` of None there, networks.py:526-527; built for the class / state_dict API and for callers that pass the noise)
+        netG = FDGenerator(img_f, ngf, output_nc=3, noise_nc=512, fuse_mode='add')
     else:
         raise TypeError('generator not implemented!')          # the reference's `raise('...')` is a TypeError too
     return init_net(netG, opt.init_type)
@@ -428,6 +428,107 @@ class DECGenerator(RGModule):
         for i in range(len(mods) - 1, -1, -1):
             dy = mods[i].tb(tape, dy, need_dx=(need_dx or i > 0))
         return dy
+
+
+class FDGenerator(RGModule):
+    """The FD-GAN decoder under the dual_gan options (networks.py:449-538; `--model_gen FD` builds it with fuse_mode='add',
+    noise_nc=512): ReID feature vector (+ noise) -> W_reid / W_noise -> ReLU -> ConvT (8, 4) -> norm -> four ConvT 4x4 / 2 blocks ->
+    ConvT -> tanh, [B, 3, 256, 128].  forward(reid_feature, noise=None): the 'add' / 'cat' modes need the noise (the reference's own
+    callers pass none and fail, see define_G)."""
+
+    def __init__(self, reid_feature_nc, ngf=64, noise_nc=3, pose_nc=18, output_nc=3, dropout=0.0, norm_layer=rnn.BatchNorm2d,
+                 fuse_mode='none'):
+        super(FDGenerator, self).__init__()
+        self.fuse_mode = fuse_mode
+        self.norm_layer = norm_layer
+        self.dropout = dropout
+        if type(norm_layer) == functools.partial:
+            self.use_bias = norm_layer.func == rnn.InstanceNorm2d
+        else:
+            self.use_bias = norm_layer == rnn.InstanceNorm2d
+        input_channel = [8, 8, 4, 2, 1]
+        if fuse_mode == 'cat':
+            nc = reid_feature_nc + noise_nc
+        elif fuse_mode == 'add':
+            nc = max(reid_feature_nc, noise_nc)
+            self.W_reid = rnn.Linear(reid_feature_nc, nc, bias=False)
+            self.W_noise = rnn.Linear(noise_nc, nc, bias=False)
+        elif fuse_mode == 'none':
+            nc = reid_feature_nc
+            self.W_reid = rnn.Linear(reid_feature_nc, nc, bias=False)
+        else:
+            raise TypeError('Wrong fuse mode, please select from [cat|add]')       # the reference's `raise (str)` is a TypeError too
+        self.de_avg = rnn.Sequential(rnn.ReLU(True), rnn.ConvTranspose2d(nc, ngf * 8, kernel_size=(8, 4), bias=self.use_bias),
+                                     norm_layer(ngf * 8), rnn.Dropout(dropout))
+        self.de_conv5 = self._make_layer_decode(ngf * input_channel[0], ngf * 8)
+        self.de_conv4 = self._make_layer_decode(ngf * input_channel[1], ngf * 4)
+        self.de_conv3 = self._make_layer_decode(ngf * input_channel[2], ngf * 2)
+        self.de_conv2 = self._make_layer_decode(ngf * input_channel[3], ngf)
+        self.de_conv1 = rnn.Sequential(rnn.ReLU(True),
+                                       rnn.ConvTranspose2d(ngf * input_channel[4], output_nc, kernel_size=4, stride=2, padding=1,
+                                                           bias=self.use_bias),
+                                       rnn.Tanh())
+
+    def _make_layer_decode(self, in_nc, out_nc):
+        return rnn.Sequential(rnn.ReLU(True),
+                              rnn.ConvTranspose2d(in_nc, out_nc, kernel_size=4, stride=2, padding=1, bias=self.use_bias),
+                              self.norm_layer(out_nc), rnn.Dropout(self.dropout))
+
+    def forward(self, reid_feature, noise=None):
+        if noise is None:
+            if self.fuse_mode != 'none':
+                raise AttributeError("FDGenerator(fuse_mode=%r) needs the noise input ('NoneType' object has no attribute 'view' in "
+                                     "the reference, networks.py:522-527)" % self.fuse_mode)
+            return super(FDGenerator, self).forward(reid_feature)
+        return super(FDGenerator, self).forward(reid_feature, noise)
+
+    def tf(self, tape, reid_feature, noise=None):
+        B = reid_feature.shape[0]
+        if self.fuse_mode == 'cat':
+            feature = ops.cat_channels([reid_feature.reshape(B, -1, 1, 1), noise.reshape(B, -1, 1, 1)])
+        else:
+            f = self.W_reid.tf(tape, reid_feature.reshape(B, -1))
+            if self.fuse_mode == 'add':
+                f = ops.add(f, self.W_noise.tf(tape, noise.reshape(B, -1)))
+            feature = f.view(B, -1, 1, 1)
+        r = ops.act_fwd(feature, ACT_RELU)
+        tape.push((r, tuple(reid_feature.shape), None if noise is None else tuple(noise.shape)))
+        x = self.de_avg[1].tf(tape, r)
+        norm, drop = self.de_avg[2], self.de_avg[3]
+        blocks = (self.de_conv5, self.de_conv4, self.de_conv3, self.de_conv2, self.de_conv1)
+        for i, blk in enumerate(blocks):
+            x = drop.tf(tape, norm.tf(tape, x, act=ACT_RELU))       # the norm of the block before + this block's ReLU in one pass
+            if i < 4:
+                x = blk[1].tf(tape, x)
+                norm, drop = blk[2], blk[3]
+            else:
+                x = blk[1].tf(tape, x, act=ACT_TANH)
+        return x
+
+    def tb(self, tape, dy, need_dx=True):
+        blocks = (self.de_conv5, self.de_conv4, self.de_conv3, self.de_conv2, self.de_conv1)
+        norms = (self.de_avg, self.de_conv5, self.de_conv4, self.de_conv3, self.de_conv2)
+        d = dy
+        for i in range(4, -1, -1):
+            d = blocks[i][1].tb(tape, d)
+            d = norms[i][2].tb(tape, norms[i][3].tb(tape, d))
+        d = self.de_avg[1].tb(tape, d)
+        r, reid_shape, noise_shape = tape.pop()
+        d = ops.act_bwd(d, r, ACT_RELU)
+        B = d.shape[0]
+        if self.fuse_mode == 'cat':
+            c_reid = 1
+            for v in reid_shape[1:]:
+                c_reid *= v
+            d_reid = ops.slice_channels(d, 0, c_reid).reshape(reid_shape)
+            d_noise = ops.slice_channels(d, c_reid, d.shape[1]).reshape(noise_shape)
+            return d_reid, d_noise
+        d2 = d.reshape(B, -1)
+        d_noise = None
+        if self.fuse_mode == 'add':
+            d_noise = self.W_noise.tb(tape, d2).reshape(noise_shape)
+        d_reid = self.W_reid.tb(tape, d2).reshape(reid_shape)
+        return d_reid, d_noise
 
 
 class PoseGenerator1(RGModule):

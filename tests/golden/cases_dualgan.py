@@ -104,3 +104,13 @@ def resize_reid_case():
     net.train()
     g = torch.Generator().manual_seed(52)
     return net, torch.tanh(torch.randn(2, 3, 32, 16, generator=g))
+
+
+def fdgen_case():
+    """`--model_gen FD`: define_G's FDGenerator(img_f, ngf, output_nc=3, noise_nc=512, fuse_mode='add') at img_f = 256"""
+    torch.manual_seed(54)
+    net = D.o_init_weights(D.OFDGenerator(256, 64, noise_nc=512, fuse_mode='add'))
+    _perturb(net, 55, 0.02)
+    net.train()
+    g = torch.Generator().manual_seed(56)
+    return net, (torch.randn(3, 256, 1, 1, generator=g), torch.randn(3, 512, generator=g))

@@ -165,6 +165,29 @@ def main():
         check(po[k].grad, pr[k].grad, "resize_reid grad " + k, 2e-4)
         out["resize_reid_g_" + k], _ = sub(pr[k].grad)
 
+    print("FDGenerator (--model_gen FD)")
+    on, (feat, noise) = C.fdgen_case()
+    rn = ref_net.FDGenerator(256, 64, output_nc=3, noise_nc=512, fuse_mode='add')
+    rn.load_state_dict(on.state_dict())
+    rn.train()
+    fo, fr = feat.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    no, nr = noise.clone().requires_grad_(True), noise.clone().requires_grad_(True)
+    yo, yr = on(fo, no), rn(fr, nr)
+    check(yo, yr, "fdgen_fwd")
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(yr.shape, generator=g)
+    yo.backward(dy)
+    yr.backward(dy)
+    check(fo.grad, fr.grad, "fdgen_dfeat", 1e-4)
+    check(no.grad, nr.grad, "fdgen_dnoise", 1e-4)
+    out["fdgen_fwd"], out["fdgen_fwd_stats"] = sub(yr)
+    out["fdgen_dfeat"], _ = sub(fr.grad)
+    out["fdgen_dnoise"], _ = sub(nr.grad)
+    pr, po = dict(rn.named_parameters()), dict(on.named_parameters())
+    for k in ["W_reid.weight", "W_noise.weight", "de_avg.1.weight", "de_conv4.1.weight", "de_conv2.2.weight", "de_conv1.1.weight"]:
+        check(po[k].grad, pr[k].grad, "fdgen grad " + k, 2e-4)
+        out["fdgen_g_" + k], _ = sub(pr[k].grad)
+
     print("DPTNGenerator")
     on, (xs, ps, pt) = C.dptn_case()
     rn = ref_net.DPTNGenerator(3, 18, 64, 256, 3, 'instance', 'LeakyReLU', False, False, 3, 3, True, 2, 2, 2)

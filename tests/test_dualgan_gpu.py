@@ -376,9 +376,8 @@ def test_dec_generators(dev):
     on, feat = C.decgen1_case()
     inner.load_state_dict(on.state_dict())
     _check(net(feat.to(dev)), on(feat), 1e-3, "define_G DEC fwd")
-    for gen in ("PoseAE", "FD"):
-        with pytest.raises(NotImplementedError):
-            N.define_G(argparse.Namespace(model_gen=gen, init_type='orthogonal', gpu_ids=[0]), 3, 18)
+    with pytest.raises(NotImplementedError):
+        N.define_G(argparse.Namespace(model_gen="PoseAE", init_type='orthogonal', gpu_ids=[0]), 3, 18)
     # AEModel with --model_gen DEC: synthesize(features) (AE_model.py:209-210), then the stand-alone D / G update on it
     from dual_gan.models.models import create_model
     from oracle import ref_dualgan as D
@@ -400,6 +399,42 @@ def test_dec_generators(dev):
     assert abs(errs["G"] - omodel.loss_G.item()) <= 1e-3 * abs(omodel.loss_G.item()), (errs, omodel.loss_G.item())
     _adam_close(model.net_G.module, omodel.net_G, 2e-4, 1, "G params (DEC)")
     _adam_close(model.net_D.module, omodel.net_D, 2e-5, 1, "D params (DEC)")
+
+
+def test_fd_generator(dev):
+    """`--model_gen FD` (FDGenerator, networks.py:449-538, 'add' fusion of the ReID vector and a 512-d noise): forward, both input
+    gradients and the parameter gradients against an fp64 run of the oracle (== reference, golden `fdgen_*`); define_G builds it, and
+    calling it the way the reference's own AEModel does — without the noise — fails as it does there."""
+    from dual_gan.models import networks as N
+    from tests.golden import cases_dualgan as C
+    from tests.golden.cases import sub
+    on, (feat, noise) = C.fdgen_case()
+    rg = _load(N.FDGenerator(256, 64, output_nc=3, noise_nc=512, fuse_mode='add'), on, dev)
+    rg.train()
+    o64 = copy.deepcopy(on).double()
+    fo, no = feat.double().requires_grad_(True), noise.double().requires_grad_(True)
+    fd, nd = feat.to(dev).requires_grad_(True), noise.to(dev).requires_grad_(True)
+    yo, y = o64(fo, no), rg(fd, nd)
+    _check(y, yo, 1e-3, "fdgen fwd")
+    ref = GOLD["fdgen_fwd"]
+    got = np.asarray(sub(y.detach().cpu())[0], dtype=np.float64).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(yo.shape, generator=g)
+    yo.backward(dy.double())
+    y.backward(dy.to(dev))
+    _check_l2(fd.grad, fo.grad, 5e-3, "fdgen dfeat")
+    _check_l2(nd.grad, no.grad, 5e-3, "fdgen dnoise")
+    _check_grads(rg, o64, 5e-3, "fdgen grads", tol_tensor=5e-2)
+    opt = argparse.Namespace(model_gen='FD', init_type='orthogonal', gpu_ids=[0])
+    net = N.define_G(opt, image_nc=3, pose_nc=18, ngf=64, img_f=256, encoder_layer=3, norm='instance', activation='LeakyReLU',
+                     use_spect=False, use_coord=False, output_nc=3, num_blocks=3)
+    inner = net.module if hasattr(net, "module") else net
+    assert type(inner).__name__ == "FDGenerator" and inner.fuse_mode == 'add'
+    inner.load_state_dict(on.state_dict())
+    _check(net(feat.to(dev), noise.to(dev)), on(feat, noise), 1e-3, "define_G FD fwd")
+    with pytest.raises(AttributeError):
+        net(feat.to(dev))                       # AEModel.synthesize(features) in the reference: noise is None
 
 
 def test_dptn_generator(dev):

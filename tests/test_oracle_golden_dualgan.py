@@ -129,6 +129,24 @@ def test_resize_reid_adaptor():
             _cmp(sub(params[key[len("resize_reid_g_"):]].grad)[0], key, 2e-4)
 
 
+def test_fd_generator():
+    net, (feat, noise) = C.fdgen_case()
+    feat, noise = feat.clone().requires_grad_(True), noise.clone().requires_grad_(True)
+    y = net(feat, noise)
+    assert tuple(y.shape) == (3, 3, 256, 128)
+    s, st = sub(y)
+    _cmp(s, "fdgen_fwd")
+    _cmp(st, "fdgen_fwd_stats")
+    g = torch.Generator().manual_seed(9)
+    y.backward(torch.randn(y.shape, generator=g))
+    _cmp(sub(feat.grad)[0], "fdgen_dfeat", 1e-4)
+    _cmp(sub(noise.grad)[0], "fdgen_dnoise", 1e-4)
+    params = dict(net.named_parameters())
+    for key in GOLD.files:
+        if key.startswith("fdgen_g_"):
+            _cmp(sub(params[key[len("fdgen_g_"):]].grad)[0], key, 2e-4)
+
+
 def test_dptn_generator():
     net, (xs, ps, pt) = C.dptn_case()
     t, s_ = net(xs, ps, pt)
