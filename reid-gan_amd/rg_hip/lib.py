@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                      # reid-gan_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC_DIR = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libreidgan_hip.so")
+LIB_PATH = os.environ.get("RG_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libreidgan_hip.so")     # RG_LIB_PATH: A/B builds of the library
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "reidgan_hip.h")
 
 _CTYPES = {
