@@ -46,8 +46,10 @@ import torch.nn.functional as F  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 peak (same guide).  The fp32 convolutions evaluate every fp32 product as SIX bf16 MFMA
                                   # products of exactly split operands (csrc/conv_igemm.hip), so the matrix pipe bounds them at
-                                  # 2500 / 6 = 416.7 fp32-equivalent TFLOP/s; `roofline.peak` stays the fp32 MFMA peak the
-                                  # BASELINE metric is priced against, `issued_mfma_*` states the bf16 side
+                                  # 2500 / 6 = 416.7 fp32-equivalent TFLOP/s: THAT is `roofline.peak` (the roof of the
+                                  # instruction actually issued); the figure against the fp32-MFMA peak that
+                                  # BASELINE.json's metric names is kept beside it as `frac_vs_fp32_mfma`
+SPLIT_BF16_PEAK_TFLOPS = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
 F8_MFMA_PEAK_TFLOPS = 5000.0      # dense fp8: v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 / e5m2 operands runs at twice the
                                   # bf16 rate (same guide, "Matrix cores"); the non-scaled 32x32x16 fp8 forms only reach 2.5 PF
 METRIC = "train-step images/sec, 256×128 ReID batch, 1/2/4/8 MI355X"
@@ -151,7 +153,7 @@ class Workload(object):
     crops = 32
     gflop_per_crop = 0.0           # algorithmic conv / linear FLOPs per crop and step (BASELINE.md §2 / SURVEY §8d)
     dtype = "f32"
-    peak = F32_MFMA_PEAK_TFLOPS
+    peak = SPLIT_BF16_PEAK_TFLOPS     # 2500 / 6: six v_mfma_f32_32x32x16_bf16 products per fp32 product
     conv_families = ("conv_fwd", "conv_dgrad", "conv_wgrad")
     kernel_note = ("conv implicit-GEMM family (conv_fwd/dgrad/wgrad_kernel, conv3x3_halo_kernel): fp32 in / fp32 out, every operand "
                    "split exactly into 3 bf16 pieces, 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 "
@@ -192,6 +194,19 @@ class FDGANStep(Workload):
         torch.manual_seed(1234)
         opt = fdgan_opt()
         self.model = FDGANModel(opt)
+        # Conditioned random weights for the two ResNet-50 trunks (the reference starts them from ImageNet / stage-1 checkpoints; with
+        # raw random filters behind frozen unit BatchNorm statistics the verification logits hit BCE's +-100 clamp on step 1 and the
+        # D_id -> G gradient of the timed step degenerates): the conditioning of tests/test_modules_gpu.py.  Same kernels, same FLOPs.
+        g = torch.Generator().manual_seed(4242)
+        with torch.no_grad():
+            for net in (self.model.net_E.module, self.model.net_Di.module):
+                cw = net.embed_model.classifier.weight
+                cw.copy_(torch.randn(cw.shape, generator=g) * 0.05)
+                for m in net.modules():
+                    if hasattr(m, "running_mean") and m.running_mean is not None and hasattr(m, "weight"):
+                        m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.05)
+                        m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.4 + 0.8)
+                        m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.2 + 0.4)
         self.model.reset_model_status()
         self.data = synth_inputs(opt.batch_size, dev, seed=100 + rank)
         torch.manual_seed(99 + rank)                             # noise z / dropout seeds differ per rank
@@ -490,6 +505,9 @@ def measure(w, args, dev, rank, world, use_dist, headline):
         alg_bytes = round(by / max(calls, 1))
         roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": w.peak, "unit": "TFLOP/s",
                 "frac": round(achieved / w.peak, 4), "traffic": traffic,
+                "peak_note": ("2500 TFLOP/s dense bf16 MFMA / %d bf16 products per fp32 product" % w.mfma_products
+                              if getattr(w, "mfma_products", 1) > 1 else "dense MFMA peak of the operand type"),
+                "frac_vs_fp32_mfma": round(achieved / F32_MFMA_PEAK_TFLOPS, 4) if w.dtype == "f32" else None,
                 "issued_mfma_tflops": round(achieved * getattr(w, "mfma_products", 1), 2) if getattr(w, "mfma_products", 1) > 1 else None,
                 "issued_mfma_peak": BF16_MFMA_PEAK_TFLOPS if getattr(w, "mfma_products", 1) > 1 else None,
                 "issued_mfma_frac": (round(achieved * w.mfma_products / BF16_MFMA_PEAK_TFLOPS, 4)

@@ -48,7 +48,10 @@ int rg_profile_enable(int on);
 int rg_profile_reset(void);
 int rg_profile_collect(double* ms, double* flops, double* bytes, long long* calls); /* synchronises events */
 
-/* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------
+/* ---- convolution: implicit GEMM, fp32 tensors, split-bf16 arithmetic on v_mfma_f32_32x32x16_bf16 ----
+ * (every fp32 operand is split exactly into three bf16 pieces and each product evaluated as the six partial products of weight
+ * >= 2^-16 with fp32 accumulation: the error model of an fp32 FMA chain, csrc/conv_igemm.hip; -DRG_MATH=1 builds the fp32-MFMA
+ * v_mfma_f32_32x32x2_f32 arithmetic of rounds 1-2)
  * Replaces nn.Conv2d / nn.ConvTranspose2d of the ResNet-50 trunk (CC/clustercontrast/models/
  * resnet_ibn_a.py:70-159, FD/reid/models/resnet.py:65-75), CustomPoseGenerator
  * (FD/fdgan/networks.py:86-138) and NLayerDiscriminator (FD/fdgan/networks.py:206-232), and
@@ -91,6 +94,10 @@ int rg_weights_to_krsc_multi(const void* table, int count, int total_blocks, rg_
 /* development knob: pin the fwd/dgrad planner's tile (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x256) and split-K count;
  * (-1, -1) releases it (same effect as the RG_CONV_FORCE="tile,splits" environment variable) */
 int rg_conv_set_force(int tile, int splits);
+/* development knob: bit mask of the conv kernel families that run on the bf16-plane operand path of csrc/conv_planes.h (operands
+ * split into their bf16 pieces once, on the way into LDS) instead of the default kernels: 1 forward, 2 data gradient, 4 weight
+ * gradient (same as RG_CONV_PL); identical results up to fp32 summation order.  Returns the previous mask. */
+int rg_conv_set_planes(int mask);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,

@@ -19,7 +19,7 @@ from rg_hip.tape import backward as _backward
 import torch.nn as nn
 
 from rg_hip import functional as RF
-from rg_hip.parallel import GradReducer
+from rg_hip.parallel import GradReducer, attach_stage_hooks
 
 from .utils.meters import AverageMeter
 
@@ -50,6 +50,9 @@ class _ReducerCache(object):
         r = self._r.get(id(optimizer))
         if r is None:
             r = self._r[id(optimizer)] = GradReducer(optimizer, modules=modules)
+            if modules is not None:
+                # the encoder's arena is reduced stage by stage from inside its backward program (layer4 first), not after it
+                attach_stage_hooks(r, *(modules if isinstance(modules, (list, tuple)) else [modules]))
         return r
 
 

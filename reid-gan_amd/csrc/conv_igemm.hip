@@ -1,5 +1,7 @@
-// Implicit-GEMM 2-D convolution for gfx950 (MI355X): forward, data-gradient and weight-gradient,
-// fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fma chain).
+// Implicit-GEMM 2-D convolution for gfx950 (MI355X): forward, data-gradient and weight-gradient, fp32 tensors.
+// Arithmetic (RG_MATH 3, the default): every fp32 operand is split exactly into three bf16 pieces and each product is evaluated as
+// six v_mfma_f32_32x32x16_bf16 partial products with fp32 accumulation (see "matrix arithmetic of one 16-deep k-tile" below);
+// RG_MATH 1 builds the round-1/2 arithmetic on v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fma chain).
 //
 // Replaces what cuDNN/ATen do for the reference's nn.Conv2d / nn.ConvTranspose2d layers:
 //   ResNet-50 trunk           CC/clustercontrast/models/resnet_ibn_a.py:70-159 (layout pin), FD/reid/models/resnet.py:65-75
@@ -653,6 +655,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     }
     store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, p.Ng, p.P * p.Q, p.d_pq, split);
 }
+
+#include "conv_planes.h"
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 with TAP REUSE (forward, and the data gradient of such a layer, which is the same convolution with
@@ -2102,6 +2106,17 @@ static void launch_reduce(hipStream_t stream, const float* ws, float* out, int64
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream, ws, out, n, splits, rsc, C, RS);
 }
 
+// RG_CONV_PL / rg_conv_set_planes: bit mask of the kernel families that run on the bf16-plane operand path (conv_planes.h:
+// operands split once on their way into LDS) instead of the round-3 kernels (fp32 LDS tiles, operands split by every reading
+// wave): 1 forward, 2 data gradient, 4 weight gradient.  Default 0: measured on the MI355X (profiles/r04_planes_vs_r03.txt) the
+// two paths are within +-3 % on the ResNet layers and the plane path is 12-14 % slower on the gather-loaded GAN layers — the
+// operand split is not what bounds these kernels — so the plane kernels stay as a tested alternative.
+static int g_planes_mask = -1;
+static bool planes_enabled(int family_bit) {
+    if (g_planes_mask < 0) g_planes_mask = getenv("RG_CONV_PL") ? atoi(getenv("RG_CONV_PL")) : 0;
+    return (g_planes_mask & family_bit) != 0;
+}
+
 // ---- tap-reuse kernel (conv3x3_halo_kernel): geometry test, plan, launch ----
 static bool halo_enabled() {
     static const int env = getenv("RG_CONV_HALO") ? atoi(getenv("RG_CONV_HALO")) : 1;
@@ -2187,6 +2202,12 @@ static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, voi
 
 }  // namespace
 
+#define RG_FWD_PL_LAUNCH(BM_, BN_, WM_, WN_)                                                                             \
+    if (bmode == 2) hipLaunchKernelGGL((conv_fwd_pl_kernel<BM_, BN_, WM_, WN_, 2, true>), grid, dim3(NT), 0, stream, p); \
+    else if (bmode == 1) hipLaunchKernelGGL((conv_fwd_pl_kernel<BM_, BN_, WM_, WN_, 1, true>), grid, dim3(NT), 0, stream, p); \
+    else if (avec) hipLaunchKernelGGL((conv_fwd_pl_kernel<BM_, BN_, WM_, WN_, 0, true>), grid, dim3(NT), 0, stream, p);  \
+    else hipLaunchKernelGGL((conv_fwd_pl_kernel<BM_, BN_, WM_, WN_, 0, false>), grid, dim3(NT), 0, stream, p)
+
 #define RG_FWD_LAUNCH(BM_, BN_, WM_, WN_)                                                                             \
     if (bmode == 2) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 2, true>), grid, dim3(NT), 0, stream, p); \
     else if (bmode == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, true>), grid, dim3(NT), 0, stream, p); \
@@ -2197,6 +2218,11 @@ static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, voi
     if (mode == 2) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(NT), 0, stream, dp);    \
     else if (mode == 1) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(NT), 0, stream, dp); \
     else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(NT), 0, stream, dp)
+
+#define RG_DGRAD_PL_LAUNCH(BM_, BN_, WM_, WN_)                                                                          \
+    if (mode == 2) hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, 2>), grid, dim3(NT), 0, stream, dp);    \
+    else if (mode == 1) hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(NT), 0, stream, dp); \
+    else hipLaunchKernelGGL((conv_dgrad_pl_kernel<BM_, BN_, WM_, WN_, 0>), grid, dim3(NT), 0, stream, dp)
 
 #define RG_TILE_SWITCH(tile, LAUNCH)      \
     switch (tile) {                       \
@@ -2342,7 +2368,8 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     p.partial_bytes = (unsigned)need;
     rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
     const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
-    RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH);
+    if (planes_enabled(1)) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
+    else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
         launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
@@ -2355,6 +2382,14 @@ extern "C" int rg_conv_set_force(int tile, int splits) {
     g_force_tile = tile;
     g_force_splits = splits;
     return RG_OK;
+}
+
+// development knob (tests, tools/bench_conv.py): kernel families on the bf16-plane operand path (bit 0 fwd, 1 dgrad, 2 wgrad);
+// returns the previous mask
+extern "C" int rg_conv_set_planes(int mask) {
+    const int old = g_planes_mask < 0 ? (getenv("RG_CONV_PL") ? atoi(getenv("RG_CONV_PL")) : 0) : g_planes_mask;
+    g_planes_mask = mask & 7;
+    return old;
 }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
@@ -2518,7 +2553,9 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
     static const int dma_env = getenv("RG_CONV_DMA") ? atoi(getenv("RG_CONV_DMA")) : 1;
-    if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {
+    if (planes_enabled(2)) {
+        RG_TILE_SWITCH(pl.tile, RG_DGRAD_PL_LAUNCH);
+    } else if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {
         // 1x1 / stride 1: both operands are lane-linear in memory -> LDS-DMA ring (conv1x1_dma_kernel)
         if (pl.tile == 0) hipLaunchKernelGGL((conv1x1_dma_kernel<128>), grid, dim3(NT), 0, stream, dp);
         else hipLaunchKernelGGL((conv1x1_dma_kernel<64>), grid, dim3(NT), 0, stream, dp);
@@ -2684,11 +2721,24 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
     if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, true, true>), grid, dim3(NT), 0, stream, p); \
     else if (veca) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NT), 0, stream, p); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NT), 0, stream, p)
-        switch (pl.tile) {
-            case 0: RG_WGRAD_LAUNCH(128, 128, 2, 2); break;
-            case 2: RG_WGRAD_LAUNCH(64, 64, 2, 2); break;
-            default: RG_WGRAD_LAUNCH(32, 256, 1, 4); break;
+#define RG_WGRAD_PL_LAUNCH(BM_, BN_, WM_, WN_)                                                                        \
+    if (vec) hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, true, true>), grid, dim3(NT), 0, stream, p); \
+    else if (veca) hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NT), 0, stream, p); \
+    else hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NT), 0, stream, p)
+        if (planes_enabled(4)) {
+            switch (pl.tile) {
+                case 0: RG_WGRAD_PL_LAUNCH(128, 128, 2, 2); break;
+                case 2: RG_WGRAD_PL_LAUNCH(64, 64, 2, 2); break;
+                default: RG_WGRAD_PL_LAUNCH(32, 256, 1, 4); break;
+            }
+        } else {
+            switch (pl.tile) {
+                case 0: RG_WGRAD_LAUNCH(128, 128, 2, 2); break;
+                case 2: RG_WGRAD_LAUNCH(64, 64, 2, 2); break;
+                default: RG_WGRAD_LAUNCH(32, 256, 1, 4); break;
+            }
         }
+#undef RG_WGRAD_PL_LAUNCH
 #undef RG_WGRAD_LAUNCH
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {

@@ -37,7 +37,7 @@ from reid.models.multi_branch import SiameseNet
 from rg_hip import functional as RF
 from rg_hip import ops
 from rg_hip import optim as roptim
-from rg_hip.parallel import DataParallel, GradReducer
+from rg_hip.parallel import DataParallel, GradReducer, attach_stage_hooks
 from rg_hip.tape import no_param_grad
 
 
@@ -151,6 +151,11 @@ class FDGANModel(object):
         if self.reducers[0].active():
             g_list = list(self.net_G.parameters())
             self.net_G.module._rg_after_backward = lambda: self.reducers[0].reduce_async(g_list)
+        # the two ResNet-50 trunks launch their ranges stage by stage from inside their backward programs (layer4 first): only the
+        # stem + layer1 bytes of E are left exposed at the tail of backward_G
+        if opt.stage == 2:
+            attach_stage_hooks(self.reducers[0], self.net_E)
+        attach_stage_hooks(self.reducers[1], self.net_Di)
 
     def _aux_stream(self):
         """Second HIP stream for work that is independent of the main chain (RG_AUX_STREAM=0 disables it).  With label

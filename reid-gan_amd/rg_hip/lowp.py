@@ -226,7 +226,7 @@ class F8Layer(object):
             # 'jit' measures first
             self.sw.prepare(w)
             self._wq = quantize_dual(w, self.sw, True, True)
-            self._wkey = key
+            self._wkey = None if ops.CAPTURING[0] else key      # recorded, not executed, inside a capture: stays stale for eager code
         return self._wq
 
 

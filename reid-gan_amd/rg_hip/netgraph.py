@@ -50,7 +50,7 @@ def _bn_layers(net):
 
 
 def graphable(net):
-    """no active Dropout (host RNG draw per call), no frozen-statistics fold groups (their refresh is conditional)"""
+    """no active Dropout (it draws a seed from the host generator per call; a replay would repeat the captured one)"""
     from .nn import Dropout
     for m in net.modules():
         if isinstance(m, Dropout) and m.training and m.p > 0.0:
@@ -95,9 +95,16 @@ def _capture_forward(net, xs, params):
     bns = _bn_layers(net)
     before = [b.__dict__.get("_nbt_pending", 0) for b in bns]
     g = torch.cuda.CUDAGraph()
-    with _capture_mode():
-        with torch.cuda.graph(g):
-            outs = net.tf(rec.tape, *rec.static_in)
+    try:
+        with _capture_mode():
+            with torch.cuda.graph(g):
+                outs = net.tf(rec.tape, *rec.static_in)
+    except Exception:
+        # the aborted program's Python side effects must not survive it: none of its kernels ran.  Cache keys are not stamped while
+        # capturing (nn._KrscCache / KrscGroup / lowp.F8Layer); the BatchNorm step counters are put back here.
+        for b, n0 in zip(bns, before):
+            b.__dict__["_nbt_pending"] = n0
+        raise
     rec.pool = g.pool()
     rec.bn_deltas = [(b, b.__dict__.get("_nbt_pending", 0) - n0) for b, n0 in zip(bns, before)
                      if b.__dict__.get("_nbt_pending", 0) != n0]

@@ -97,7 +97,9 @@ class _KrscCache(object):
         key = self._krsc_key()
         if getattr(self, "_wk_key", None) != key or ops.CAPTURING[0]:
             self._wk = ops.weights_to_krsc(self.weight.detach())
-            self._wk_key = key
+            # inside a capture nothing executes (and the copy lives in the capture's pool): the key stays stale, so eager code that
+            # runs after the capture — including the fallback of a capture that FAILED — rebuilds the copy for real
+            self._wk_key = None if ops.CAPTURING[0] else key
         return self._wk
 
 
@@ -137,8 +139,8 @@ class KrscGroup(object):
                 raise RuntimeError("KrscGroup: a parameter moved while a network program is being captured")
             self._build()
         ops.lib.rg_weights_to_krsc_multi(ops._p(self.table), len(self.members), self.blocks, ops._stream())
-        for m in self.members:
-            m._wk_key = m._krsc_key()
+        for m in self.members:           # (recorded, not executed, inside a capture: keys stay stale there — see _KrscCache._krsc)
+            m._wk_key = None if ops.CAPTURING[0] else m._krsc_key()
 
     def get(self, m):
         if not m.__dict__.get("_krsc_member"):

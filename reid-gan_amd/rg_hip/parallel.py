@@ -125,6 +125,55 @@ class GradReducer(object):
                 self._pending.append(work)
                 pos = end
 
+    def reduce_stage(self, tape, params):
+        """Launch the all-reduce of one finished STAGE of a backward program that is still running (rg_hip.resnet_trunk.trunk_tb
+        calls this through `_rg_stage_hook`).  `p.grad` is not assigned yet at that point: a parameter takes part when the gradient
+        the program recorded for it (`tape.grads`) IS its arena view and is its first contribution of the step — exactly the
+        gradients that are final; anything else (accumulated contributions, gradients outside the arena) is left to the
+        `reduce()` / `reduce_async()` at the end of the pass, which skips the ranges launched here.
+        The collective is ordered behind the weight-gradient side stream of the running backward session as well as behind the
+        calling stream (the stage's filter gradients run there), without making the calling stream wait for either."""
+        if not self.active():
+            return 0
+        a = self.arena
+        index = getattr(a, "_rg_index", None)
+        if index is None:
+            index = a._rg_index = {id(p): i for i, p in enumerate(a.params)}
+        offs = []
+        for p in params:
+            i = index.get(id(p))
+            g = tape.grads.get(id(p)) if i is not None else None
+            v = getattr(p, "_rg_grad", None)
+            if g is None or v is None or p.grad is not None or g.data_ptr() != v.data_ptr():
+                continue
+            offs.append((a.offsets[i], a.offsets[i] + p.numel()))
+        offs.sort()
+        ranges = []
+        for s, e in offs:
+            if any(ds <= s < de for ds, de in self._done):
+                continue
+            if ranges and 0 <= s - ranges[-1][1] <= 64:
+                ranges[-1][1] = e
+            else:
+                ranges.append([s, e])
+        if not ranges:
+            return 0
+        launched = 0
+        with _behind_side_stream(a.flat_grad):
+            for s, e in ranges:
+                self._done.append((s, e))
+                pos = s
+                while pos < e:
+                    end = min(e, pos + self.bucket_elems)
+                    self._pending.append(dist.all_reduce(a.flat_grad[pos:end], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+                    launched += 1
+                    pos = end
+        return launched
+
+    def in_flight(self):
+        return len(self._pending)
+
     def wait(self):
         for w in self._pending:
             w.wait()
@@ -134,6 +183,51 @@ class GradReducer(object):
     def reduce(self):
         self.reduce_async(None)
         self.wait()
+
+
+class _behind_side_stream(object):
+    """Context: collectives launched inside are ordered behind BOTH the current stream and the weight-gradient side stream of the
+    backward session running on it (rg_hip.ops.side_call), by issuing them from the side stream after it has been made to wait for
+    an event of the current stream.  CPU tensors / no open session: a no-op."""
+
+    def __init__(self, tensor):
+        self.ctx = None
+        if tensor.is_cuda:
+            from . import ops
+            main, sess = ops._side_session(create=False)
+            if sess is not None and sess.depth > 0 and sess.used:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                sess.stream.wait_event(ev)
+                self.ctx = torch.cuda.stream(sess.stream)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+def attach_stage_hooks(reducer, *modules):
+    """Give every ResNet trunk under `modules` the stage hook of `reducer`: its gradient all-reduce is then launched stage by stage
+    from inside the trunk's backward program (layer4 first) instead of after it.  Returns the number of trunks found.  Harmless on
+    one rank (the hook returns at once while the reducer is inactive)."""
+    from .resnet_trunk import TVResNet
+    n = 0
+    for root in modules:
+        root = getattr(root, "module", root)
+        for m in root.modules():
+            mods = None
+            if isinstance(m, TVResNet):
+                mods = m.trunk_modules()
+            elif hasattr(m, "base") and isinstance(getattr(m, "base"), nn.Sequential) and len(m.base) >= 8:
+                mods = list(m.base)                   # clustercontrast ResNet: `base` is the trunk as a Sequential
+            if mods is not None and hasattr(mods[0], "weight"):
+                mods[0].__dict__["_rg_stage_hook"] = reducer.reduce_stage
+                n += 1
+    return n
 
 
 class GatherHandle(object):

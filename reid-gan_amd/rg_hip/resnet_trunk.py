@@ -165,14 +165,28 @@ def trunk_tf(tape, mods, x):
 
 
 def trunk_tb(tape, mods, dy, need_dx=True):
+    """Backward program of the trunk.  `mods[0]._rg_stage_hook(tape, params)` — set by rg_hip.parallel.attach_stage_hooks — is called
+    as each stage (layer4 .. layer1, then the stem) has launched its last weight gradient: the data-parallel all-reduce of that
+    stage's range of the gradient arena starts there and runs under the backward of the stages below (the arena keeps a stage's
+    parameters adjacent, so a stage is one element range)."""
     conv1, bn1, _relu, maxpool = mods[0], mods[1], mods[2], mods[3]
-    blocks = [blk for layer in mods[4:] for blk in layer]
-    for i in range(len(blocks) - 1, -1, -1):
-        # every block's input except the first one's (the max-pool output) is the previous block's ReLU output: its
-        # backward runs in this block's conv1 dgrad epilogue, so the block below receives an already masked gradient
-        dy = blocks[i].tb(tape, dy, dy_masked=(i != len(blocks) - 1), mask_input=(i != 0))
+    hook = getattr(conv1, "_rg_stage_hook", None)
+    layers = [list(layer) for layer in mods[4:]]
+    nblk = sum(len(layer) for layer in layers)
+    i = nblk
+    for li in range(len(layers) - 1, -1, -1):
+        for blk in reversed(layers[li]):
+            i -= 1
+            # every block's input except the first one's (the max-pool output) is the previous block's ReLU output: its
+            # backward runs in this block's conv1 dgrad epilogue, so the block below receives an already masked gradient
+            dy = blk.tb(tape, dy, dy_masked=(i != nblk - 1), mask_input=(i != 0))
+        if hook is not None:
+            hook(tape, [p for blk in layers[li] for p in blk.parameters()])
     dy = maxpool.tb(tape, dy)
-    return rnn.conv_bn_tb(tape, conv1, bn1, dy, need_dx=need_dx)
+    dx = rnn.conv_bn_tb(tape, conv1, bn1, dy, need_dx=need_dx)
+    if hook is not None:
+        hook(tape, list(conv1.parameters()) + list(bn1.parameters()))
+    return dx
 
 
 def bn_all_eval(module):

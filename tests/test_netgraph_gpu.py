@@ -122,3 +122,50 @@ def test_dropout_network_is_not_graphed_and_busy_records_are_not_reused(dev):
         for a, b in zip(ng.parameters(), ne.parameters()):
             assert torch.equal(a.grad, b.grad), it
     assert max(rec for _, rec, _ in NG.stats(ng).values()) == 2
+
+
+def test_uncapturable_network_falls_back_to_eager_with_fresh_caches(dev):
+    """A program that cannot be captured (host read-back in tf) runs eagerly — and the capture attempt leaves nothing behind: the
+    (r,s)-major filter copies are rebuilt for real (their cache keys are not stamped inside a capture) and the BatchNorm step
+    counters are restored.  Compared step by step with a twin that never tries to capture."""
+    import warnings
+    from rg_hip import nn as rnn, netgraph as NG
+    from rg_hip.tape import RGModule
+
+    class Net(RGModule):
+        def __init__(self):
+            super(Net, self).__init__()
+            self.c1 = rnn.Conv2d(16, 16, 3, 1, 1)
+            self.bn = rnn.BatchNorm2d(16)
+            self.c2 = rnn.Conv2d(16, 8, 3, 1, 1)
+
+        def tf(self, tape, x):
+            h = self.bn.tf(tape, self.c1.tf(tape, x), act=rnn.ACT_RELU)
+            float(h[0, 0, 0, 0])                          # host read-back: illegal inside a stream capture
+            return self.c2.tf(tape, h)
+
+        def tb(self, tape, dy, need_dx=True):
+            return self.c1.tb(tape, self.bn.tb(tape, self.c2.tb(tape, dy)), need_dx=need_dx)
+
+    torch.manual_seed(3)
+    ng, ne = Net().to(dev), Net().to(dev)
+    ne.load_state_dict(ng.state_dict())
+    ng.__dict__["_rg_graph"] = True
+    og, oe = torch.optim.SGD(ng.parameters(), lr=0.1), torch.optim.SGD(ne.parameters(), lr=0.1)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for it in range(NG.WARMUP + 3):
+            x = torch.randn(4, 16, 16, 8, device=dev, generator=torch.Generator(device=dev).manual_seed(50 + it))
+            outs = []
+            for net, opt in ((ng, og), (ne, oe)):
+                opt.zero_grad()
+                y = net(x)
+                y.pow(2).sum().backward()
+                opt.step()
+                outs.append(y.detach())
+            assert torch.equal(outs[0], outs[1]), it
+            for a, b in zip(ng.parameters(), ne.parameters()):
+                assert torch.equal(a, b), it
+    assert any("not capturable" in str(w.message) for w in caught)
+    assert all(rec == 0 and not ok for _, rec, ok in NG.stats(ng).values())
+    assert int(ng.bn.num_batches_tracked) == int(ne.bn.num_batches_tracked)

@@ -858,3 +858,30 @@ def test_batchnorm_train_single_launch(dev, shape, act):
     m2, i2 = ops.bn_stats(x.to(dev), None, None, 1e-5, 0.1)
     _close(m2, mean, tol=1e-6, name="mean vs bn_stats")
     _close(i2, invstd, tol=1e-5, name="invstd vs bn_stats")
+
+
+PLANES_CASES = [c for c in CONV_CASES if c[4] > 4 and c[1] > 4][:28]
+
+
+@pytest.mark.parametrize("case", PLANES_CASES)
+def test_conv_planes_kernels(dev, case):
+    """the bf16-plane operand path (csrc/conv_planes.h: operands split once on their way into LDS, fragments by ds_read_b128 /
+    ds_read_b64_tr_b16) — not the default (it measured no faster) but kept correct: same bounds as the default
+    kernels, every loader variant (float4 along k / along the rows, blocked scalar gathers, ragged tiles, split-K)"""
+    ops = _ops()
+    from rg_hip import lib as rglib
+    N, C, H, W, K, KH, KW, s, p = _geom(case)
+    g = torch.Generator().manual_seed(4321 + N * 7 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, KH, KW, generator=g) / math.sqrt(C * KH * KW)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv2d(xd, wd, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy.double())
+    old = rglib.lib.rg_conv_set_planes(7)
+    try:
+        _close(ops.conv2d_fwd(x.to(dev), w.to(dev), s, p), y_ref, name="fwd (planes)")
+        _close(ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p), xd.grad, name="dgrad (planes)")
+        _close(ops.conv2d_wgrad(x.to(dev), dy.to(dev), (K, C, KH, KW), s, p), wd.grad, tol=5e-5, name="wgrad (planes)")
+    finally:
+        rglib.lib.rg_conv_set_planes(old)

@@ -260,3 +260,105 @@ def test_cluster_memory_gather_and_ordered_update_world2():
         assert bank_err == 0.0, (rank, bank_err)      # every replica applied the same updates in the same order
         assert grad_err < 1e-6, (rank, grad_err)      # the input gradient used the PRE-update bank and stays local
     assert res[0][3] == res[1][3]
+
+
+# ---- stage-bucketed all-reduce launched from inside the trunk's backward program (rg_hip.resnet_trunk.trunk_tb) ----------------
+class _FakeBlock(object):
+    """stands in for a bottleneck block on the CPU: its backward writes a rank- and tensor-dependent gradient straight into the
+    arena views and records them on the tape, as the HIP weight-gradient kernels do"""
+
+    def __init__(self, shapes, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+        self.seed = seed
+
+    def parameters(self):
+        return list(self.ps)
+
+    def fill(self, tape, rank):
+        for j, p in enumerate(self.ps):
+            g = torch.Generator().manual_seed(1000 * self.seed + 10 * j + rank)
+            p._rg_grad.copy_(torch.randn(p.shape, generator=g))
+            tape.add_grad(p, p._rg_grad)
+
+    def tb(self, tape, dy, dy_masked=False, mask_input=False):
+        self.fill(tape, _FakeBlock.rank)
+        return dy
+
+
+class _FakeStem(_FakeBlock):
+    @property
+    def weight(self):
+        return self.ps[0]
+
+
+class _FakePool(object):
+    def tb(self, tape, dy):
+        return dy
+
+
+def _stage_worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=90))
+    try:
+        from rg_hip import resnet_trunk
+        from rg_hip.tape import Tape
+        _FakeBlock.rank = rank
+        conv1, bn1 = _FakeStem([(8, 3, 7, 7)], 1), _FakeBlock([(8,), (8,)], 2)
+        layers = [[_FakeBlock([(8, 8, 1, 1), (8,), (8,), (8, 8, 3, 3)], 10 * li + b) for b in range(nb)]
+                  for li, nb in ((1, 3), (2, 4), (3, 6), (4, 3))]
+        mods = [conv1, bn1, None, _FakePool()] + layers
+        params = conv1.parameters() + bn1.parameters() + [p for layer in layers for blk in layer for p in blk.parameters()]
+
+        def run(bucketed):
+            arena = Arena(params)
+            for p in params:
+                p.grad = None
+            red = GradReducer(_FakeOptimizer(arena), bucket_mb=0.001)
+            if bucketed:
+                conv1.__dict__["_rg_stage_hook"] = red.reduce_stage
+            else:
+                conv1.__dict__.pop("_rg_stage_hook", None)
+            tape = Tape(param_grad=True)
+            # the stem's backward (conv_bn_tb) is a HIP program: a CPU stand-in with the same side effects
+            old = resnet_trunk.rnn.conv_bn_tb
+            resnet_trunk.rnn.conv_bn_tb = lambda tape, c, b, dy, need_dx=True: (c.fill(tape, rank), b.fill(tape, rank), dy)[2]
+            try:
+                resnet_trunk.trunk_tb(tape, mods, torch.zeros(1), need_dx=False)
+            finally:
+                resnet_trunk.rnn.conv_bn_tb = old
+            in_flight = red.in_flight()
+            for p in params:                                  # what tape._NetFn.backward does after the program returned
+                p.grad = p._rg_grad
+            red.reduce()
+            return in_flight, arena.flat_grad.clone()
+
+        n_plain, g_plain = run(False)
+        n_stage, g_stage = run(True)
+        q.put((rank, n_plain, n_stage, bool(torch.equal(g_plain, g_stage)), float(g_stage.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage_bucketed_allreduce_inside_trunk_backward_world2():
+    """bucketed (one launch per finished stage, from inside trunk_tb) == unbucketed (one reduce() after the backward) bit for bit,
+    and the collectives of all five stages are in flight when trunk_tb returns"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.terminate()
+        assert p.exitcode == 0
+    sums = set()
+    for rank, n_plain, n_stage, same, s in res:
+        assert n_plain == 0, n_plain                          # nothing is launched before the end without the hook
+        assert n_stage >= 5, n_stage                          # layer4, layer3, layer2, layer1, stem (>= 3 asked for)
+        assert same, rank
+        sums.add(round(s, 3))
+    assert len(sums) == 1                                     # both ranks hold the same reduced gradients
