@@ -285,6 +285,13 @@ int rg_act_bwd_sum(const float* dy, const float* y_act, float* g, float* sum_g, 
 int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
                      const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma, int K, int M,
                      rg_stream_t stream);
+/* rg_conv2d_wgrad + rg_bn_fold_wgrad in one call (same arguments): with split-K the fold finishes inside the reduction launch
+ * (one launch, one pass over G less per folded layer) */
+int rg_conv2d_wgrad_fold(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
+                         int SH, int SW, int PH, int PW, int P, int Q, const float* w, const float* scale,
+                         const float* invstd, const float* running_mean, const float* sum_g, const float* partials,
+                         int n_slices, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes,
+                         rg_stream_t stream);
 int rg_bn_slices(int N, int C, int HW);
 int rg_act_bwd_partial(const float* dy, const float* y_act, float* g, float* part, int N, int C, int HW, int act, float slope,
                        rg_stream_t stream);

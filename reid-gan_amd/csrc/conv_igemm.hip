@@ -1960,6 +1960,81 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     }
 }
 
+// Split-K reduction of the weight gradient of a convolution whose frozen-statistics BatchNorm is folded into it (norm.hip, "conv +
+// frozen-statistics BatchNorm"): ONE workgroup per filter row k sums the slabs of its row (float4 columns, the summation tree of
+// splitk_reduce_vec_kernel: same G bit for bit), and finishes the fold while G is in registers — dgamma[k] = invstd (sum_m W G - mean
+// sum g), dbeta[k] = sum g (from the slice partials), dW = scale[k] G.  Replaces splitk_reduce_vec_kernel + bn_fold_wgrad_kernel:
+// one launch, one write and one read of G less per folded layer (106 layers per FD-GAN step).  M % 4 == 0, 16-byte aligned buffers.
+__global__ __launch_bounds__(256) void splitk_reduce_fold_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                 const float* __restrict__ w, int M, int64_t n, int splits,
+                                                                 const float* __restrict__ scale, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ mean, const float* __restrict__ sum_g,
+                                                                 const float* __restrict__ part, int S, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dgamma) {
+    __shared__ float4 red[4][64];
+    __shared__ float redf[16];
+    const int k = blockIdx.x;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int M4 = M >> 2;
+    const int64_t n4 = n >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    const float4* f4 = reinterpret_cast<const float4*>(w);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const float sc = scale[k];
+    float dot = 0.f;
+    for (int c0 = 0; c0 < M4; c0 += 64) {
+        const int c = c0 + tx;
+        const int64_t i = (int64_t)k * M4 + c;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (c < M4) {
+            int q = ty;
+            for (; q + 12 < splits; q += 16) {
+                const float4 a = w4[(int64_t)q * n4 + i], b = w4[(int64_t)(q + 4) * n4 + i];
+                const float4 cc = w4[(int64_t)(q + 8) * n4 + i], d = w4[(int64_t)(q + 12) * n4 + i];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+                s0.x += cc.x; s0.y += cc.y; s0.z += cc.z; s0.w += cc.w;
+                s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            }
+            for (; q + 4 < splits; q += 8) {
+                const float4 a = w4[(int64_t)q * n4 + i], b = w4[(int64_t)(q + 4) * n4 + i];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            }
+            if (q < splits) {
+                const float4 a = w4[(int64_t)q * n4 + i];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            }
+        }
+        red[ty][tx] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+        __syncthreads();
+        if (ty == 0 && c < M4) {
+            const float4 r0 = red[0][tx], r1 = red[1][tx], r2 = red[2][tx], r3 = red[3][tx];
+            const float4 v = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                                         (r0.w + r1.w) + (r2.w + r3.w));
+            if (dgamma) {
+                const float4 wv = f4[i];
+                dot += (wv.x * v.x + wv.y * v.y) + (wv.z * v.z + wv.w * v.w);
+            }
+            o4[i] = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        }
+        __syncthreads();
+    }
+    float sg = 0.f;
+    if (part) {                       // channel sum of g from slice / tile partials (the tree of bn_fold_wgrad_kernel)
+        float t = 0.f;
+        for (int s = threadIdx.x; s < S; s += 256) t += part[(int64_t)k * S + s];
+        sg = rg_block_sum(t, redf);
+        if (dbeta && threadIdx.x == 0) dbeta[k] = sg;
+    } else if (sum_g) {
+        sg = sum_g[k];
+    }
+    if (dgamma) {
+        const float t = rg_block_sum(dot, redf);
+        if (threadIdx.x == 0) dgamma[k] = invstd[k] * (t - mean[k] * sg);
+    }
+}
+
 // algorithmic HBM bytes of one conv launch: one read of each operand + one write of the result (fp32)
 #define ALG_BYTES (4.0 * ((double)N * C * H * W + (double)K * C * KH * KW + (double)N * K * P * Q))
 
@@ -2658,9 +2733,27 @@ extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW,
     return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
 }
 
-extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH,
-                               int KW, int SH, int SW, int PH, int PW, int P, int Q, void* workspace,
-                               size_t workspace_bytes, hipStream_t stream) {
+extern "C" int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
+                                const float* sum_g, const float* partials, int n_slices, float* dbeta, float* dgamma, int K,
+                                int M, hipStream_t stream);        // norm.hip
+
+namespace {
+struct FoldArgs {                 // folded frozen-statistics BatchNorm behind the convolution (rg_conv2d_wgrad_fold)
+    const float *w, *scale, *invstd, *mean, *sum_g, *partials;
+    int n_slices;
+    float *dbeta, *dgamma;
+};
+static int fold_after(const FoldArgs* f, float* dw, int K, int M, hipStream_t stream) {
+    return rg_bn_fold_wgrad(f->w, dw, f->scale, f->invstd, f->mean, f->sum_g, f->partials, f->n_slices, f->dbeta, f->dgamma, K, M,
+                            stream);
+}
+static bool fold_fused_enabled() {
+    static const int env = getenv("RG_WGRAD_FOLD_FUSED") ? atoi(getenv("RG_WGRAD_FOLD_FUSED")) : 1;
+    return env != 0;
+}
+
+int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW, int PH,
+               int PW, int P, int Q, const FoldArgs* fold, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (int e = validate("rg_conv2d_wgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(x && dy && dw, "rg_conv2d_wgrad: null tensor");
     RG_REQUIRE(KH < 65536 && KW < 65536, "rg_conv2d_wgrad: filter too large");
@@ -2685,7 +2778,8 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
             if (int e = rg::check_launch("rg_conv2d_wgrad(thin)")) return e;
             const int64_t n = (int64_t)K * p.Ng;
             launch_reduce(stream, static_cast<const float*>(workspace), dw, n, slices, 0, C, KH * KW);
-            return rg::check_launch("rg_conv2d_wgrad(thin reduce)");
+            if (int e = rg::check_launch("rg_conv2d_wgrad(thin reduce)")) return e;
+            return fold ? fold_after(fold, dw, K, p.Ng, stream) : RG_OK;
         }
     }
     const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
@@ -2743,8 +2837,40 @@ extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;
         if (via_ws) {
             const int64_t n = (int64_t)p.M * p.Ng;
+            const bool al16 = ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dw) |
+                                reinterpret_cast<uintptr_t>(fold ? fold->w : nullptr)) & 15) == 0;
+            if (fold && !rsc && (p.Ng & 3) == 0 && al16 && fold_fused_enabled()) {
+                // reduction + BatchNorm-fold finish in one launch (one workgroup per filter)
+                hipLaunchKernelGGL(splitk_reduce_fold_kernel, dim3(p.M), dim3(256), 0, stream, static_cast<const float*>(workspace), dw,
+                                   fold->w, p.Ng, n, pl.splits, fold->scale, fold->invstd, fold->mean, fold->sum_g, fold->partials,
+                                   fold->n_slices, fold->dbeta, fold->dgamma);
+                return rg::check_launch("rg_conv2d_wgrad(reduce + fold)");
+            }
             launch_reduce(stream, static_cast<const float*>(workspace), dw, n, pl.splits, rsc ? 1 : 0, C, KH * KW);
         }
     }
-    return rg::check_launch("rg_conv2d_wgrad(reduce)");
+    if (int e = rg::check_launch("rg_conv2d_wgrad(reduce)")) return e;
+    return fold ? fold_after(fold, dw, K, C * KH * KW, stream) : RG_OK;
+}
+}  // namespace
+
+extern "C" int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH,
+                               int KW, int SH, int SW, int PH, int PW, int P, int Q, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+    return wgrad_impl(x, dy, dw, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, nullptr, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient of a convolution with a folded frozen-statistics BatchNorm behind it, finished in the same call:
+// G = wgrad(x, dy); dgamma = invstd (sum_m w G - mean sum_g); dbeta = sum_g (when it comes as slice partials); dw = scale G
+// (arguments as rg_bn_fold_wgrad; dgamma / dbeta may be NULL).  With split-K the finish runs inside the reduction launch.
+extern "C" int rg_conv2d_wgrad_fold(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
+                                    int SH, int SW, int PH, int PW, int P, int Q, const float* w, const float* scale,
+                                    const float* invstd, const float* running_mean, const float* sum_g, const float* partials,
+                                    int n_slices, float* dbeta, float* dgamma, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+    RG_REQUIRE(w && scale, "rg_conv2d_wgrad_fold: null filters / scale");
+    RG_REQUIRE(!dgamma || (invstd && running_mean && (sum_g || partials)), "rg_conv2d_wgrad_fold: dgamma needs invstd, mean and the sums");
+    RG_REQUIRE(!partials || n_slices > 0, "rg_conv2d_wgrad_fold: partials need their slice count");
+    const FoldArgs f{w, scale, invstd, running_mean, sum_g, partials, n_slices, dbeta, dgamma};
+    return wgrad_impl(x, dy, dw, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, &f, workspace, workspace_bytes, stream);
 }

@@ -678,11 +678,11 @@ def conv_bn_tb(tape, conv, bn, dy, need_dx=True, residual=None, dy_masked=False,
         og = tape.grad_out(bn.weight) if want_g else None
         dgamma = (og if og is not None else torch.empty_like(f.scale)) if want_g else None
 
-        def finish(G):
-            ops.bn_fold_wgrad(w, G, f.scale, f.invstd, bn.running_mean, sg, dgamma, partials=part,
-                              dbeta=dbeta if part is not None else None)
+        # G = wgrad(x, g) and the fold's finish (dgamma, dbeta, dW = scale G) in ONE call: with split-K the finish runs inside the
+        # reduction launch (rg_conv2d_wgrad_fold)
         dw = ops.conv2d_wgrad(x, g, conv.weight.shape, conv.stride, conv.padding,
-                              out=tape.grad_out(conv.weight) if want_w else None, side=True, after=finish)
+                              out=tape.grad_out(conv.weight) if want_w else None, side=True,
+                              fold=(w, f.scale, f.invstd, bn.running_mean, sg, part, dbeta if part is not None else None, dgamma))
         if want_w:
             tape.add_grad(conv.weight, dw)
         if want_g:

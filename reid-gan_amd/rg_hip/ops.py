@@ -265,9 +265,10 @@ def side_call(fn, *operands, worth=True):
     return fn()
 
 
-def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None):
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, after=None, fold=None):
     """dw[K][C][KH][KW]; side=True launches on the backward session's side stream; `after(dw)` is enqueued right
-    behind the wgrad kernels on the same stream (e.g. the BatchNorm-fold finishing pass)."""
+    behind the wgrad kernels on the same stream; `fold` = (w, scale, invstd, running_mean, sum_g, partials, dbeta, dgamma): the
+    folded-BatchNorm finish of rg_conv2d_wgrad_fold (dw = scale G, dgamma, dbeta) runs inside the same call."""
     if side and _SIDE["on"] and side_worth(2e-9 * dy.numel() * w_shape[1] * w_shape[2] * w_shape[3]):
         main, sess = _side_session(create=False)
         if sess is not None and sess.depth > 0:
@@ -277,8 +278,8 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
             ev.record(main)
             sess.stream.wait_event(ev)
             with torch.cuda.stream(sess.stream):
-                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after)
-            sess.refs.append((x, dy, dw, after))         # the hook's closure keeps ITS operands alive too
+                conv2d_wgrad(x, dy, w_shape, stride, padding, out=dw, after=after, fold=fold)
+            sess.refs.append((x, dy, dw, after, fold))   # the hook's closure / the fold's operands stay alive too
             sess.used = True
             return dw
     x, dy = _chk(x, "x"), _chk(dy, "dy")
@@ -292,8 +293,14 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, out=None, side=False, afte
     dw = out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     nbytes = _ws_query("rg_conv2d_wgrad_workspace", N, C, K, KH, KW, P, Q)
     ws = workspace(nbytes, x.device)
-    lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
-                        _stream())
+    if fold is not None:
+        fw, fscale, finvstd, fmean, fsum, fpart, fdbeta, fdgamma = fold
+        lib.rg_conv2d_wgrad_fold(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(fw), _p(fscale),
+                                 _p(finvstd), _p(fmean), _p(fsum), _p(fpart), fpart.shape[1] if fpart is not None else 0,
+                                 _p(fdbeta), _p(fdgamma), _p(ws), ws.numel(), _stream())
+    else:
+        lib.rg_conv2d_wgrad(_p(x), _p(dy), _p(dw), N, C, H, W, K, KH, KW, sh, sw, ph, pw, P, Q, _p(ws), ws.numel(),
+                            _stream())
     if after is not None:
         after(dw)
     return dw

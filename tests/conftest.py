@@ -12,11 +12,23 @@ for p in (PKG, REPO):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a second / third parametrisation of a >= 5 s step test whose path another test of the "
+                                       "default run already compares with the oracle; run with -m 'gpu and slow' or RG_RUN_SLOW=1 "
+                                       "(tools/gpu_tests_all.sh)")
 
 
 def pytest_collection_modifyitems(config, items):
     """no test may hang the suite: a stuck multi-process rendezvous (or a GPU run-away) fails after a bound instead
     (pytest-timeout is part of the image; without it the markers are inert)"""
+    # the default `-m gpu` run keeps one representative of every step test; the duplicates sit behind the `slow` marker
+    expr = config.getoption("-m", default="") or ""
+    if os.environ.get("RG_RUN_SLOW") != "1" and "slow" not in expr:
+        kept, dropped = [], []
+        for item in items:
+            (dropped if item.get_closest_marker("slow") is not None else kept).append(item)
+        if dropped:
+            config.hook.pytest_deselected(items=dropped)
+            items[:] = kept
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:

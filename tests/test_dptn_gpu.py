@@ -82,7 +82,7 @@ def _remove_kinks(hip_nets, oracle_nets):
                 mod.negative_slope = 1.0
 
 
-@pytest.mark.parametrize("gan_mode", ["hinge", "vanilla"])
+@pytest.mark.parametrize("gan_mode", ["hinge", pytest.param("vanilla", marks=pytest.mark.slow)])
 def test_dptn_gradients_exact_without_kinks(dev, gan_mode):
     """Every gradient of the DPTN step (D update, then G update through the updated-forward D) against an fp64 run of the
     oracle with the LeakyReLU kinks removed: max-norm per tensor <= 1e-4 of the tensor's largest entry (fp32 InstanceNorm over
@@ -121,7 +121,10 @@ def test_dptn_gradients_exact_without_kinks(dev, gan_mode):
     print("worst gradient max-norm error without kinks: %.2e" % worst)
 
 
-@pytest.mark.parametrize("gan_mode,with_vgg", [("hinge", False), ("vanilla", False), ("wgangp", False), ("hinge", True)])
+# default run: the hinge step (BASELINE config 5's mode) and the wgangp step (the gradient-penalty path); the vanilla mode and the
+# VGG variant repeat the same programs with another loss head (-m "gpu and slow")
+@pytest.mark.parametrize("gan_mode,with_vgg", [("hinge", False), pytest.param("vanilla", False, marks=pytest.mark.slow), ("wgangp", False),
+                                               pytest.param("hinge", True, marks=pytest.mark.slow)])
 def test_dptn_step_matches_oracle_and_reference_fixture(dev, gan_mode, with_vgg):
     """Step 0 (identical weights on both sides): every loss and both generated images at 1e-3, against the oracle AND against
     the values recorded from the reference's own DPTNModel.  Step 1 follows one Adam update of G and D: Adam's first step is
@@ -280,7 +283,7 @@ def test_dptn_step_fp8_declared_tolerance(dev):
             assert abs(got[k] - ref[k]) <= 5e-2 * abs(ref[k]) + atol, "step %d %s: fp8 %.5f vs fp32 oracle %.5f" % (step, k, got[k], ref[k])
 
 
-@pytest.mark.parametrize("conv_dtype", ["fp32", "fp8"])
+@pytest.mark.parametrize("conv_dtype", [pytest.param("fp32", marks=pytest.mark.slow), "fp8"])      # fp32: also test_netgraph_gpu / test_fullsize_gpu
 def test_dptn_steps_are_bit_identical_between_runs(dev, conv_dtype):
     """three optimizer steps from the same state twice: identical losses, generated images and parameters, bit for bit — the
     split-K reductions, the integer-atomic amax collection of the fp8 scaling states, the side-stream weight gradients and the

@@ -184,7 +184,7 @@ def test_reid_resnet_head_variants(dev):
 
 # (norm='instance' cannot run in the reference either: en_avg ends in a 1x1 map and torch's instance_norm refuses
 # a single spatial element in training mode)
-@pytest.mark.parametrize("norm,cl", [("batch", 0), ("batch", 3)])
+@pytest.mark.parametrize("norm,cl", [pytest.param("batch", 0, marks=pytest.mark.slow), ("batch", 3)])      # cl = 3 runs every layer of cl = 0 plus the skips
 def test_generator(dev, norm, cl):
     from oracle import ref_torch as O
     import fdgan.networks as N

@@ -14,7 +14,8 @@ CONV_F8 = "conv_f8"
 FAMILY = {
     # conv_igemm.hip
     "conv_fwd_kernel": CONV, "conv_dgrad_kernel": CONV, "conv_wgrad_kernel": CONV, "conv3x3_halo_kernel": CONV,
-    "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV,
+    "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV, "splitk_reduce_fold_kernel": CONV,
+    "conv_fwd_pl_kernel": CONV, "conv_dgrad_pl_kernel": CONV, "conv_wgrad_pl_kernel": CONV,      # conv_planes.h
     "conv_dgrad_smallc_kernel": CONV, "conv_dgrad_smallc_px_kernel": CONV, "conv_fwd_k1_kernel": CONV,
     "conv_wgrad_k1_kernel": CONV, "conv_splitk_finish_kernel": CONV, "splitk_reduce_kernel": CONV,
     "conv_splitk_finish_vec_kernel": CONV, "splitk_reduce_vec_kernel": CONV, "conv_wgrad_k1_px4_kernel": CONV,
@@ -83,12 +84,12 @@ def family_of(kernel):
 
 
 def source_kernels(csrc_dir):
-    """every __global__ kernel name defined in csrc/*.hip"""
+    """every __global__ kernel name defined in csrc/*.hip and the kernel headers they include (csrc/*.h)"""
     import glob
     import os
     import re
     names = set()
-    for f in sorted(glob.glob(os.path.join(csrc_dir, "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(csrc_dir, "*.hip")) + glob.glob(os.path.join(csrc_dir, "*.h"))):
         t = open(f).read()
         for m in re.finditer(r"__global__", t):
             mm = re.search(r"\bvoid\s+(\w+)\s*\(", t[m.end():m.end() + 400])
