@@ -98,6 +98,11 @@ int rg_conv_set_force(int tile, int splits);
  * split into their bf16 pieces once, on the way into LDS) instead of the default kernels: 1 forward, 2 data gradient, 4 weight
  * gradient (same as RG_CONV_PL); identical results up to fp32 summation order.  Returns the previous mask. */
 int rg_conv_set_planes(int mask);
+/* The generic fwd / dgrad / wgrad kernels exist in two implementations (default kernels and the plane path above); unless one is
+ * forced (rg_conv_set_planes, RG_CONV_TUNE=0) the first call of a geometry outside a stream capture times both on the launch
+ * stream and the faster serves that geometry from then on (the first call's output already comes from it).  Returns the number of
+ * geometries measured so far; out[0] / out[1] (int[2], may be NULL): how many chose the default kernels / the plane path. */
+int rg_conv_tune_stats(int* out);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,

@@ -33,6 +33,9 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -2181,15 +2184,67 @@ static void launch_reduce(hipStream_t stream, const float* ws, float* out, int64
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rg::cdiv64(n, 64)), dim3(256), 0, stream, ws, out, n, splits, rsc, C, RS);
 }
 
-// RG_CONV_PL / rg_conv_set_planes: bit mask of the kernel families that run on the bf16-plane operand path (conv_planes.h:
-// operands split once on their way into LDS) instead of the round-3 kernels (fp32 LDS tiles, operands split by every reading
-// wave): 1 forward, 2 data gradient, 4 weight gradient.  Default 0: measured on the MI355X (profiles/r04_planes_vs_r03.txt) the
-// two paths are within +-3 % on the ResNet layers and the plane path is 12-14 % slower on the gather-loaded GAN layers — the
-// operand split is not what bounds these kernels — so the plane kernels stay as a tested alternative.
+// Two implementations of the generic fwd / dgrad / wgrad kernels exist: the round-3 kernels (fp32 LDS tiles, every reading wave
+// splits its fragments) and the bf16-plane path of conv_planes.h (operands split once on their way into LDS).  Neither wins
+// everywhere: measured per layer they differ by up to +-20 % in both directions (profiles/r04_planes_vs_r03.txt: the plane path
+// gains on the deep 1x1 layers and the 1x1 / shifted weight gradients, loses on the gather-loaded 4x4 layers).  So the choice is
+// MEASURED, once per (family, geometry, plan): the first call of a geometry outside a stream capture runs both (one warm-up and
+// one timed launch each, HIP events on the launch stream), keeps the faster (the plane path has to win by 3 %) and re-runs it if
+// it was not the last one, so the output of every call — the first included — comes from the kernel that serves the geometry
+// from then on: run-to-run bit-identity inside a process is untouched.  RG_CONV_TUNE=0: always the round-3 kernels.
+// RG_CONV_PL / rg_conv_set_planes(mask): force the plane path per family (1 forward, 2 data gradient, 4 weight gradient).
 static int g_planes_mask = -1;
 static bool planes_enabled(int family_bit) {
     if (g_planes_mask < 0) g_planes_mask = getenv("RG_CONV_PL") ? atoi(getenv("RG_CONV_PL")) : 0;
     return (g_planes_mask & family_bit) != 0;
+}
+static bool tune_enabled() {
+    static const int env = getenv("RG_CONV_TUNE") ? atoi(getenv("RG_CONV_TUNE")) : 1;
+    return env != 0;
+}
+typedef std::array<int, 16> TuneKey;
+static std::map<TuneKey, int> g_tune;
+static std::mutex g_tune_mu;
+
+// run(0): round-3 kernel, run(1): plane path (each: the kernel launch only; split-K finishers follow the choice).  Returns the
+// implementation that ran LAST (= the chosen one).
+template <typename Run>
+static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, Run run) {
+    if (planes_enabled(family_bit)) { run(1); return 1; }
+    if (!tune_enabled()) { run(0); return 0; }
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    auto it = g_tune.find(key);
+    if (it != g_tune.end()) { run(it->second); return it->second; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        run(0);                       // no host synchronisation inside a capture: round-3 kernel, nothing recorded
+        return 0;
+    }
+    hipEvent_t ev[4];
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) ok = hipEventCreate(&ev[i]) == hipSuccess && ok;
+    float t[2] = {0.f, 0.f};
+    if (ok) {
+        run(0); run(1);               // warm-up (first launch of a code object loads it)
+        for (int c = 0; c < 2; ++c) {
+            ok = hipEventRecord(ev[2 * c], stream) == hipSuccess && ok;
+            run(c);
+            ok = hipEventRecord(ev[2 * c + 1], stream) == hipSuccess && ok;
+        }
+        ok = hipEventSynchronize(ev[3]) == hipSuccess && ok;
+        for (int c = 0; c < 2 && ok; ++c) ok = hipEventElapsedTime(&t[c], ev[2 * c], ev[2 * c + 1]) == hipSuccess;
+    }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
+    if (!ok) {
+        (void)hipGetLastError();
+        run(0);
+        return 0;
+    }
+    const int choice = t[1] < 0.97f * t[0] ? 1 : 0;
+    g_tune[key] = choice;
+    if (choice == 0) run(0);          // the plane path ran last: the result must come from the chosen kernel
+    return choice;
 }
 
 // ---- tap-reuse kernel (conv3x3_halo_kernel): geometry test, plan, launch ----
@@ -2443,8 +2498,12 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
     p.partial_bytes = (unsigned)need;
     rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
     const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
-    if (planes_enabled(1)) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
-    else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
+    const TuneKey tk = {1, N, C, H, W, K, KH, KW, SH, SW, PH, PW, bmode * 2 + (avec ? 1 : 0), pl.tile, pl.splits,
+                        (int)(p.ep.res != nullptr) * 4 + p.ep.act};
+    choose_impl(1, tk, stream, [&](int impl) {
+        if (impl) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
+        else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
+    });
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
         launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
@@ -2465,6 +2524,16 @@ extern "C" int rg_conv_set_planes(int mask) {
     const int old = g_planes_mask < 0 ? (getenv("RG_CONV_PL") ? atoi(getenv("RG_CONV_PL")) : 0) : g_planes_mask;
     g_planes_mask = mask & 7;
     return old;
+}
+
+// number of (family, geometry) entries the first-call kernel chooser has measured so far; out[0] / out[1] (may be NULL): how many
+// of them went to the round-3 kernels / the plane path
+extern "C" int rg_conv_tune_stats(int* out) {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    int n[2] = {0, 0};
+    for (const auto& kv : g_tune) ++n[kv.second ? 1 : 0];
+    if (out) { out[0] = n[0]; out[1] = n[1]; }
+    return n[0] + n[1];
 }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
@@ -2628,15 +2697,19 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
     static const int dma_env = getenv("RG_CONV_DMA") ? atoi(getenv("RG_CONV_DMA")) : 1;
-    if (planes_enabled(2)) {
-        RG_TILE_SWITCH(pl.tile, RG_DGRAD_PL_LAUNCH);
-    } else if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {
-        // 1x1 / stride 1: both operands are lane-linear in memory -> LDS-DMA ring (conv1x1_dma_kernel)
-        if (pl.tile == 0) hipLaunchKernelGGL((conv1x1_dma_kernel<128>), grid, dim3(NT), 0, stream, dp);
-        else hipLaunchKernelGGL((conv1x1_dma_kernel<64>), grid, dim3(NT), 0, stream, dp);
-    } else {
-        RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
-    }
+    const TuneKey tk = {2, N, C, H, W, K, KH, KW, SH, SW, PH, PW, mode, pl.tile, pl.splits,
+                        (int)(p.ep.res != nullptr) * 16 + (int)(p.ep.mask != nullptr) * 8 + (int)(p.ep.rowsum != nullptr) * 4 + p.ep.act};
+    choose_impl(2, tk, stream, [&](int impl) {
+        if (impl) {
+            RG_TILE_SWITCH(pl.tile, RG_DGRAD_PL_LAUNCH);
+        } else if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {
+            // 1x1 / stride 1: both operands are lane-linear in memory -> LDS-DMA ring (conv1x1_dma_kernel)
+            if (pl.tile == 0) hipLaunchKernelGGL((conv1x1_dma_kernel<128>), grid, dim3(NT), 0, stream, dp);
+            else hipLaunchKernelGGL((conv1x1_dma_kernel<64>), grid, dim3(NT), 0, stream, dp);
+        } else {
+            RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
+        }
+    });
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
         launch_finish(stream, p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
@@ -2819,19 +2892,22 @@ int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, 
     if (vec) hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, true, true>), grid, dim3(NT), 0, stream, p); \
     else if (veca) hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NT), 0, stream, p); \
     else hipLaunchKernelGGL((conv_wgrad_pl_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NT), 0, stream, p)
-        if (planes_enabled(4)) {
-            switch (pl.tile) {
-                case 0: RG_WGRAD_PL_LAUNCH(128, 128, 2, 2); break;
-                case 2: RG_WGRAD_PL_LAUNCH(64, 64, 2, 2); break;
-                default: RG_WGRAD_PL_LAUNCH(32, 256, 1, 4); break;
+        const TuneKey tk = {4, N, C, H, W, K, KH, KW, SH, SW, PH, PW, (vec ? 2 : 0) + (veca ? 1 : 0) + p.wshift * 4, pl.tile, pl.splits, 0};
+        choose_impl(4, tk, stream, [&](int impl) {
+            if (impl) {
+                switch (pl.tile) {
+                    case 0: RG_WGRAD_PL_LAUNCH(128, 128, 2, 2); break;
+                    case 2: RG_WGRAD_PL_LAUNCH(64, 64, 2, 2); break;
+                    default: RG_WGRAD_PL_LAUNCH(32, 256, 1, 4); break;
+                }
+            } else {
+                switch (pl.tile) {
+                    case 0: RG_WGRAD_LAUNCH(128, 128, 2, 2); break;
+                    case 2: RG_WGRAD_LAUNCH(64, 64, 2, 2); break;
+                    default: RG_WGRAD_LAUNCH(32, 256, 1, 4); break;
+                }
             }
-        } else {
-            switch (pl.tile) {
-                case 0: RG_WGRAD_LAUNCH(128, 128, 2, 2); break;
-                case 2: RG_WGRAD_LAUNCH(64, 64, 2, 2); break;
-                default: RG_WGRAD_LAUNCH(32, 256, 1, 4); break;
-            }
-        }
+        });
 #undef RG_WGRAD_PL_LAUNCH
 #undef RG_WGRAD_LAUNCH
         if (int e = rg::check_launch("rg_conv2d_wgrad")) return e;

@@ -121,9 +121,10 @@ def test_dptn_gradients_exact_without_kinks(dev, gan_mode):
     print("worst gradient max-norm error without kinks: %.2e" % worst)
 
 
-# default run: the hinge step (BASELINE config 5's mode) and the wgangp step (the gradient-penalty path); the vanilla mode and the
-# VGG variant repeat the same programs with another loss head (-m "gpu and slow")
-@pytest.mark.parametrize("gan_mode,with_vgg", [("hinge", False), pytest.param("vanilla", False, marks=pytest.mark.slow), ("wgangp", False),
+# default run: the hinge step (BASELINE config 5's mode); the vanilla / wgangp modes and the VGG variant repeat the same programs with
+# another loss head (-m "gpu and slow")
+@pytest.mark.parametrize("gan_mode,with_vgg", [("hinge", False), pytest.param("vanilla", False, marks=pytest.mark.slow),
+                                               pytest.param("wgangp", False, marks=pytest.mark.slow),      # (the penalty itself: test_gradient_penalty_against_reference_fixture)
                                                pytest.param("hinge", True, marks=pytest.mark.slow)])
 def test_dptn_step_matches_oracle_and_reference_fixture(dev, gan_mode, with_vgg):
     """Step 0 (identical weights on both sides): every loss and both generated images at 1e-3, against the oracle AND against
@@ -283,7 +284,10 @@ def test_dptn_step_fp8_declared_tolerance(dev):
             assert abs(got[k] - ref[k]) <= 5e-2 * abs(ref[k]) + atol, "step %d %s: fp8 %.5f vs fp32 oracle %.5f" % (step, k, got[k], ref[k])
 
 
-@pytest.mark.parametrize("conv_dtype", [pytest.param("fp32", marks=pytest.mark.slow), "fp8"])      # fp32: also test_netgraph_gpu / test_fullsize_gpu
+# default run: tests/test_netgraph_gpu.py compares graphed with eager steps bit for bit in both arithmetics, tests/test_fullsize_gpu.py
+# two config-2 steps between runs; these two repeat that for the eager DPTN step alone
+@pytest.mark.slow
+@pytest.mark.parametrize("conv_dtype", ["fp32", "fp8"])
 def test_dptn_steps_are_bit_identical_between_runs(dev, conv_dtype):
     """three optimizer steps from the same state twice: identical losses, generated images and parameters, bit for bit — the
     split-K reductions, the integer-atomic amax collection of the fp8 scaling states, the side-stream weight gradients and the

@@ -885,3 +885,28 @@ def test_conv_planes_kernels(dev, case):
         _close(ops.conv2d_wgrad(x.to(dev), dy.to(dev), (K, C, KH, KW), s, p), wd.grad, tol=5e-5, name="wgrad (planes)")
     finally:
         rglib.lib.rg_conv_set_planes(old)
+
+
+def test_conv_kernel_choice_is_measured_once_and_results_do_not_change(dev):
+    """the first call of a geometry times the round-3 kernel and the plane path and keeps the faster; the output of that first call
+    already comes from the kept kernel, so repeating the call gives the same bits (fwd, dgrad, wgrad)"""
+    import ctypes
+    ops = _ops()
+    from rg_hip import lib as rglib
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(6, 48, 20, 12, generator=g).to(dev)             # a geometry no other test uses
+    w = (torch.randn(80, 48, 3, 3, generator=g) * 0.05).to(dev)
+    before = rglib.lib.rg_conv_tune_stats(None)
+    y1 = ops.conv2d_fwd(x, w, 2, 1)
+    dy = torch.randn(y1.shape, generator=g).to(dev)
+    dx1 = ops.conv2d_dgrad(dy, w, (20, 12), 2, 1)
+    dw1 = ops.conv2d_wgrad(x, dy, (80, 48, 3, 3), 2, 1)
+    cnt = (ctypes.c_int * 2)()
+    after = rglib.lib.rg_conv_tune_stats(ctypes.addressof(cnt))
+    assert after == before + 3 and cnt[0] + cnt[1] == after, (before, after, list(cnt))
+    for _ in range(2):
+        assert torch.equal(ops.conv2d_fwd(x, w, 2, 1), y1)
+        assert torch.equal(ops.conv2d_dgrad(dy, w, (20, 12), 2, 1), dx1)
+        assert torch.equal(ops.conv2d_wgrad(x, dy, (80, 48, 3, 3), 2, 1), dw1)
+    assert rglib.lib.rg_conv_tune_stats(None) == after
+    _close(y1, F.conv2d(x.double().cpu(), w.double().cpu(), stride=2, padding=1), name="fwd (chosen kernel)")

@@ -5,6 +5,8 @@
 #           -> gpurun_out/<tag>_c<C>_kernel_summary_serial.csv   (per-kernel calls / avg / ms per step)
 #   pmc:    two SEPARATE counter passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains)
 #           -> gpurun_out/<tag>_c<C>_pmc_{FETCH,WRITE}_SIZE.csv and the per-family fold gpurun_out/<tag>_pmc_traffic.json
+#   sq:     one SQ counter pass (matrix-pipe busy cycles, VALU / MFMA instruction counts, wave wait cycles)
+#           -> gpurun_out/<tag>_c<C>_pmc_sq.csv and the per-kernel occupancy table gpurun_out/<tag>_c<C>_mfma_busy.txt
 # Copy what should be judged from gpurun_out/ into profiles/.
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
@@ -28,4 +30,10 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
   # steps per pass: 1 warm-up + 1 timed (+ 4 capture steps for the configurations with graphed networks)
   psteps=2; case $c in 4a|5) psteps=6;; esac
   python tools/pmc_traffic.py gpurun_out/${tag}_c${c}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_c${c}_pmc_WRITE_SIZE.csv $psteps gpurun_out/${tag}_pmc_traffic.json $c
+fi
+if [ "$what" = sq ] || [ "$what" = all ]; then
+  rm -rf /tmp/pmc_${c}_sq
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_${c}_sq -- python3 bench.py --config $c --no-others --no-cpu-baseline --steps 1 --warmup 1 --profile-steps 0 > /dev/null 2> gpurun_out/${tag}_c${c}_pmc_sq.err || exit 1
+  python tools/prof_summary.py /tmp/pmc_${c}_sq gpurun_out/${tag}_c${c}_pmc_sq.csv || exit 1
+  python tools/pmc_busy.py gpurun_out/${tag}_c${c}_pmc_sq.csv gpurun_out/${tag}_c${c}_mfma_busy.txt 20
 fi
