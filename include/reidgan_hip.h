@@ -11,7 +11,8 @@
  * Contract (every function):
  *   - returns 0 (RG_OK) or a negative status; rg_last_error() gives the message (thread local);
  *   - plain pointers to DEVICE memory and sizes; tensors are contiguous fp32 NCHW, labels int64;
- *   - asynchronous on `stream`; never allocates, frees or synchronises (rg_profile_collect excepted);
+ *   - asynchronous on `stream`; never allocates, frees or synchronises (rg_profile_collect excepted; the first call of a
+ *     convolution geometry outside a stream capture waits once for a two-kernel timing on `stream`: rg_conv_tune_stats);
  *   - scratch comes from the caller: `workspace`/`workspace_bytes`, sized by the *_workspace query;
  *   - pointers must be 16-byte aligned (torch allocations are).
  */

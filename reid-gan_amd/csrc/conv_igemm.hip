@@ -115,12 +115,14 @@ struct ConvP {
 
 struct DgradClass {
     int r0, s0, nrh, nrw, Hc, Wc, Ngc, Kgc, ntiles, poff;      // poff: first row-sum column block of the class
+    int ktps, coff;                                            // split-K: k-tiles per split of THIS class, its first partial column
     FastDiv d_taps, d_nrw, d_hw, d_w;
 };
 
 struct DgradP {
     ConvP c;
     DgradClass cls[4];
+    int ng_total;                                              // strided split-K: columns of one partial row (sum of the classes' Ngc)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -476,6 +478,29 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
         }
     }
     store_tile_epilogue_any<T>(p, acc, ob, (unsigned)PIX * 4u, mrow0, pcol);
+}
+
+// raw accumulators of a tile to partial[(split * M + m) * ncols + col0 + n] (strided data gradient with split-K: the classes'
+// columns side by side, col0 = the class' first column)
+template <typename T>
+__device__ __forceinline__ void store_tile_partial_cols(const ConvP& p, const floatx16 (&acc)[T::TM][T::TN], int m0, int n0, int wm,
+                                                        int wn, int lane, int Ng, int col0, int ncols, int split) {
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int mrow0 = m0 + wm * T::WTM + 4 * kh;
+    const rsrc_t ro = make_rsrc(p.partial, p.partial_bytes);
+    const unsigned rstride = (unsigned)ncols * 4u;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int nn = n0 + wn * T::WTN + j * 32 + l32;
+        const unsigned ob = nn < Ng ? (unsigned)((((int64_t)split * p.M + mrow0) * ncols + col0 + nn) * 4) : OOB;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
+                bstore(ro, (mrow0 + mo < p.M && ob != OOB) ? ob + (unsigned)mo * rstride : OOB, acc[i][j][r]);
+            }
+    }
 }
 
 // A operand loader shared by fwd (weights [M][Kg], k contiguous): float4 along k (AVEC) or scalar.
@@ -856,6 +881,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     const int wm = wid / WN, wn = wid % WN;
     const int nwg = p.m_tiles * cl.ntiles;
     if ((int)blockIdx.x >= nwg) return;
+    if (p.partial && (p.SH > 1 || p.SW > 1) && cl.Kgc <= 0) return;      // strided split-K: the finisher writes tap-less classes itself
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -1004,8 +1030,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
     };
 
     const int nk = (cl.Kgc + BK - 1) / BK;
-    const int kt_begin = split * p.ktiles_per_split;
-    int kt_end = kt_begin + p.ktiles_per_split;
+    const int kt_begin = split * cl.ktps;
+    int kt_end = kt_begin + cl.ktps;
     if (kt_end > nk) kt_end = nk;
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
@@ -1025,6 +1051,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(RG_WAVES))) 
 
     if (p.SH == 1 && p.SW == 1) {       // one class: output pixels are contiguous, shared epilogue (+ split-K)
         store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * WN + wn);
+        return;
+    }
+    if (p.partial) {                    // strided split-K: raw accumulators to partial[split][m][coff + n] (conv_splitk_finish_strided_kernel)
+        store_tile_partial_cols<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, cl.coff, dp.ng_total, split);
         return;
     }
     // strided classes: pixel (hc, wc) of the class lands on (ah + SH*hc, aw + SW*wc); same fused epilogue
@@ -1589,6 +1619,40 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_vec_kernel(const float
             if (!(mk.w > 0.f)) v.w = 0.f;
         }
         *reinterpret_cast<float4*>(out + o) = v;
+    }
+}
+
+// Strided data gradient with split-K: partial[s][m][col] holds the classes' columns side by side; column col of class ci is pixel
+// (img, hc, wc) of that stride-parity class = output pixel (ah + SH hc, aw + SW wc).  One thread per OUTPUT element (m, img, h, w):
+// its class and column follow from (h, w), the stores are coalesced along w and the partial loads are SW interleaved unit-stride
+// streams (one per column parity).  Same epilogue as the one-class finisher.
+__global__ __launch_bounds__(256) void conv_splitk_finish_strided_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                         const DgradP dp, int splits, FastDiv d_hw, FastDiv d_w,
+                                                                         FastDiv d_nhw) {
+    const ConvP& p = dp.c;
+    const int ncols = dp.ng_total;
+    const int HW = p.H * p.W, NHW = p.N * HW;
+    const int64_t total = (int64_t)p.M * NHW, slab = (int64_t)p.M * ncols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = fdiv((int)i, d_nhw);
+        const int r = (int)i - m * NHW;
+        const int im = fdiv(r, d_hw);
+        const int hw = r - im * HW;
+        const int h = fdiv(hw, d_w), w = hw - h * p.W;
+        const int ah = h % p.SH, aw = w % p.SW;               // SH, SW <= 2
+        const DgradClass& cl = dp.cls[ah * p.SW + aw];
+        const int col = cl.coff + (im * cl.Hc + h / p.SH) * cl.Wc + w / p.SW;
+        const float* pp = partial + (int64_t)m * ncols + col;
+        float v = 0.f;
+        if (cl.Kgc > 0)                                       // classes without filter taps (1x1 / stride 2: three of four) hold no partials
+            for (int s = 0; s < splits; ++s) v += pp[(int64_t)s * slab];
+        const int64_t o = ((int64_t)im * p.M + m) * HW + hw;
+        if (p.ep.scale) v *= p.ep.scale[m];
+        if (p.ep.shift) v += p.ep.shift[m];
+        if (p.ep.res) v += p.ep.res[o];
+        v = rg_apply_act(v, p.ep.act, p.ep.slope);
+        if (p.ep.mask && !(p.ep.mask[o] > 0.f)) v = 0.f;
+        out[o] = v;
     }
 }
 
@@ -2537,7 +2601,31 @@ extern "C" int rg_conv_tune_stats(int* out) {
 }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
-    if (SH != 1 || SW != 1) return 0;
+    if (SH != 1 || SW != 1) {
+        // strided: the classes' partial columns side by side (all N*H*W pixels); the plan depends on the mean class depth, which
+        // does not depend on the padding (the classes' tap counts are a permutation) — planned as dgrad_impl does for pad 0
+        if (SH > 2 || SW > 2) return 0;
+        int64_t ng_eff = 0;
+        double kw_sum = 0.0;
+        for (int ah = 0; ah < SH; ++ah)
+            for (int aw = 0; aw < SW; ++aw) {
+                const int r0 = ah % SH, s0 = aw % SW;
+                const int nrh = r0 < KH ? (KH - r0 + SH - 1) / SH : 0, nrw = s0 < KW ? (KW - s0 + SW - 1) / SW : 0;
+                const int Hc = ah < H ? (H - ah + SH - 1) / SH : 0, Wc = aw < W ? (W - aw + SW - 1) / SW : 0;
+                const int64_t ngc = (int64_t)N * Hc * Wc;
+                if (nrh * nrw > 0) {
+                    ng_eff += ngc;
+                    kw_sum += (double)ngc * K * nrh * nrw;
+                }
+            }
+        if (ng_eff <= 0 || C <= 4) return 0;
+        static const int strided_split = getenv("RG_DGRAD_STRIDED_SPLIT") ? atoi(getenv("RG_DGRAD_STRIDED_SPLIT")) : 1;
+        if (!strided_split || (int64_t)C * N * H * W >= (1ll << 31)) return 0;
+        const int64_t kg_deep = (int64_t)K * ((KH + SH - 1) / SH) * ((KW + SW - 1) / SW);      // the deepest class (dgrad_impl plans on it)
+        const GemmPlan pl = plan_gemm(C, ng_eff, kg_deep, true);
+        // one split more than planned: a padding whose classes order differently may plan one more
+        return pl.splits > 1 ? (size_t)(pl.splits + 1) * C * (size_t)N * H * W * sizeof(float) : 0;
+    }
     const GemmPlan pl = plan_gemm(C, (int64_t)N * H * W, (int64_t)K * KH * KW, true);
     size_t need = pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
     int hpv, wh, slab;
@@ -2664,13 +2752,32 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
             kw_sum += (double)dp.cls[i].Ngc * dp.cls[i].Kgc;
         }
     const int64_t kg_eff = ng_eff > 0 ? (int64_t)(kw_sum / (double)ng_eff) : kg_max;
-    GemmPlan pl = one_class ? plan_gemm(p.M, ng_max, kg_max, true) : plan_gemm(p.M, ng_eff > 0 ? ng_eff : ng_max, kg_eff, false);
-    if (!one_class) pl.ktiles_per_split = 1 << 30;       // planned on the MEAN depth: every class runs its full reduction
-    const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
-    if (!dry && (need > workspace_bytes || (need && !workspace))) {
+    // Strided classes may split their reductions too (RG_DGRAD_STRIDED_SPLIT=0: never): the 3x3 / 1x1 stride-2 layers of layer3 /
+    // layer4 have 32-128 tiles for 256 CUs and class depths that differ 4x (1, 2, 2 and 4 taps); every class is cut into the same
+    // number of splits of ITS depth, the partial columns of the classes lie side by side and conv_splitk_finish_strided_kernel
+    // scatters the sums to the classes' pixels with the fused epilogue.
+    static const int strided_split = getenv("RG_DGRAD_STRIDED_SPLIT") ? atoi(getenv("RG_DGRAD_STRIDED_SPLIT")) : 1;
+    // (planned on the DEEPEST class when splitting is allowed: the classes' workgroups start together, so an unsplit launch lasts
+    // as long as its deepest class — 4 taps against a mean of 2.25 for 3x3 / 2 — and planning on the mean depth kept the layer4
+    // gradients unsplit on 64 x 64 tiles: l4.0.conv2 95 -> 71 us, l4.0.down 83 -> 71 us with four splits, profiles/r04_strided_dgrad.txt)
+    const bool ssplit = strided_split != 0 && ng_eff > 0 && (int64_t)p.M * N * H * W < (1ll << 31);
+    GemmPlan pl = one_class ? plan_gemm(p.M, ng_max, kg_max, true)
+                            : plan_gemm(p.M, ng_eff > 0 ? ng_eff : ng_max, ssplit ? kg_max : kg_eff, ssplit);
+    int64_t ng_total = 0;
+    for (int i = 0; i < SH * SW; ++i) {
+        dp.cls[i].coff = (int)ng_total;
+        ng_total += dp.cls[i].Ngc;
+    }
+    dp.ng_total = (int)ng_total;
+    size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)(one_class ? ng_max : ng_total) * sizeof(float) : 0;
+    if (need >= (1ull << 31) || (!dry && (need > workspace_bytes || (need && !workspace)))) {
         pl.splits = 1;
         pl.ktiles_per_split = 1 << 30;
+        need = 0;
     }
+    for (int i = 0; i < SH * SW; ++i)          // k-tiles per split: the plan's for one class, each class' own depth / splits otherwise
+        dp.cls[i].ktps = one_class ? pl.ktiles_per_split
+                                   : (pl.splits > 1 ? (int)rg::cdiv64(rg::cdiv64(dp.cls[i].Kgc > 0 ? dp.cls[i].Kgc : 1, BK), pl.splits) : (1 << 30));
     p.m_tiles = pl.m_tiles;
     int nt_max = 0, nt_sum = 0;
     for (int i = 0; i < SH * SW; ++i) {
@@ -2712,7 +2819,9 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     });
     if (pl.splits > 1) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
-        launch_finish(stream, p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+        if (one_class) launch_finish(stream, p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
+        else hipLaunchKernelGGL(conv_splitk_finish_strided_kernel, dim3(finish_grid((int64_t)p.M * N * H * W)), dim3(256), 0, stream,
+                                p.partial, dx, dp, pl.splits, make_fastdiv(H * W), make_fastdiv(W), make_fastdiv(N * H * W));
     }
     return rg::check_launch("rg_conv2d_dgrad");
 }

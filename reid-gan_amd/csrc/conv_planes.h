@@ -253,6 +253,7 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
     const int wm = wid / WN, wn = wid % WN;
     const int nwg = p.m_tiles * cl.ntiles;
     if ((int)blockIdx.x >= nwg) return;
+    if (p.partial && (p.SH > 1 || p.SW > 1) && cl.Kgc <= 0) return;      // strided split-K: the finisher writes tap-less classes itself
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int mt = tile % p.m_tiles, nt = tile / p.m_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
     constexpr int SA = decltype(sa)::STEPS, S = SA + decltype(sb)::STEPS;
     const unsigned fa = lds0 + LA::frag_base(lane, wm * T::WTM), fb = lds0 + LA::BYTES + LB::frag_base(lane, wn * T::WTN);
     const int nk = (cl.Kgc + BK - 1) / BK;
-    const int kt_begin = split * p.ktiles_per_split;
-    int kt_end = kt_begin + p.ktiles_per_split;
+    const int kt_begin = split * cl.ktps;
+    int kt_end = kt_begin + cl.ktps;
     if (kt_end > nk) kt_end = nk;
     pl_mainloop<T, LA, LB, S>(fa, fb, kt_begin, kt_end, acc, load_tile, [&](unsigned wbuf, int s) {
         if (s < SA) {
@@ -401,6 +402,10 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
 
     if (p.SH == 1 && p.SW == 1) {       // one class: output pixels are contiguous, shared epilogue (+ split-K)
         store_tile_nchw<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, p.H * p.W, cl.d_hw, split, (cl.poff + nt) * WN + wn);
+        return;
+    }
+    if (p.partial) {                    // strided split-K (conv_splitk_finish_strided_kernel)
+        store_tile_partial_cols<T>(p, acc, m0, n0, wm, wn, lane, cl.Ngc, cl.coff, dp.ng_total, split);
         return;
     }
     // strided classes: pixel (hc, wc) of the class lands on (ah + SH*hc, aw + SW*wc); same fused epilogue

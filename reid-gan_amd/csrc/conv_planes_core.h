@@ -278,3 +278,101 @@ __device__ __forceinline__ void pl_mainloop_ws(bool producer, unsigned fa, unsig
         tile(BoolTag<false>{});
     }
 }
+
+// ---- 16x16x32 variant ------------------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16 issues the same FLOPs per cycle as the 32x32x16 form, but the chip holds a higher clock on it under
+// load (MI355X_MICROARCH.md, DVFS item 7; tools/micro/mfma_shape_bench.hip).  Operand tiles are 32 deep: PL_R = [piece][k group of
+// 8][row][8 k] (rows XOR-ed with 2 x group inside their aligned 8-row block: the four 8-byte store runs of a 16-lane group land on
+// four different bank quarters, the 16-byte fragment reads stay 256 contiguous bytes per 16 lanes), PL_T = [piece][32 k][row] with
+// the 16-column halves swapped on odd k groups (the two k groups a 32-lane half reads transposed fall on disjoint banks).
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int BK32 = 32;
+
+__device__ __forceinline__ floatx4 mfma16_bf16(const int4r& a, const int4r& b, const floatx4& c) {
+#ifdef NO_MFMA
+    floatx4 r = c;
+    r[0] += __builtin_bit_cast(float, a[0] ^ b[0]); r[1] += __builtin_bit_cast(float, a[1] ^ b[1]);
+    r[2] += __builtin_bit_cast(float, a[2] ^ b[2]); r[3] += __builtin_bit_cast(float, a[3] ^ b[3]);
+    return r;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+template <int KIND, int ROWS>
+struct PlTile32 {
+    static constexpr int GROUP = ROWS * 16;                     // PL_R: bytes between k groups
+    static constexpr int PITCH = pl_tpitch(ROWS);               // PL_T: bytes between k rows
+    static constexpr int PIECE = KIND == PL_R ? 4 * GROUP : 32 * PITCH;
+    static constexpr int BYTES = 3 * PIECE;
+    static constexpr int BLK = KIND == PL_R ? 256 : 32;         // bytes between consecutive 16-row blocks of a fragment read
+    // fragment read of the 16-row block b (0 ..) of the wave's rows: base(lane, row0, b & 1) + (b >> 1) * 2 * BLK for PL_T (the
+    // swapped halves make odd and even blocks use different bases), base + b * BLK for PL_R; row0 % 32 == 0
+    __device__ __forceinline__ static unsigned frag_base(int lane, int row0, int odd) {
+        const int g = lane >> 4, i = lane & 15;
+        if (KIND == PL_R) return (unsigned)(g * GROUP + ((row0 + 16 * odd + i) ^ (2 * g)) * 16);
+        const int k = 8 * g + (i >> 2), col = (row0 + 16 * odd + 4 * (i & 3)) ^ (16 * (g & 1));
+        return (unsigned)(k * PITCH + col * 2);
+    }
+    __device__ __forceinline__ static int4r frag(unsigned a) {
+        if (KIND == PL_R) return *(const lds_int4_t*)(size_t)(a);
+        const short4r lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(size_t)(a));
+        const short4r hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(size_t)(a + 4 * PITCH));
+        const int2r l = __builtin_bit_cast(int2r, lo), h = __builtin_bit_cast(int2r, hi);
+        return int4r{l[0], l[1], h[0], h[1]};
+    }
+    __device__ __forceinline__ static unsigned off_rk(int row, int k) {
+        if (KIND == PL_R) return (unsigned)((k >> 3) * GROUP + ((row ^ (2 * (k >> 3))) * 16) + (k & 7) * 2);
+        return (unsigned)(k * PITCH + (row ^ (16 * ((k >> 3) & 1))) * 2);
+    }
+};
+
+// one 32-deep k-step of a (TM x 32) x (TN x 32) wave tile as (2 TM) x (2 TN) blocks of 16 x 16; ra(ib, pc) / rb(jb, pc): piece pc of
+// 16-row block ib / jb; hook(slot) behind MFMA number slot (0 .. 24 TM TN - 1)
+template <int TM, int TN, typename RA, typename RB, typename Hook>
+__device__ __forceinline__ void mma_pl16(RA ra, RB rb, floatx4 (&acc)[2 * TM][2 * TN], Hook hook) {
+    Split3 a[2 * TM], b[2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i) { a[i].lo = ra(i, 2); a[i].hi = ra(i, 0); a[i].mid = ra(i, 1); }
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) { b[j].hi = rb(j, 0); b[j].lo = rb(j, 2); b[j].mid = rb(j, 1); }
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {
+            const int s0 = 6 * (j * 2 * TM + i);
+            floatx4& c = acc[i][j];
+            c = mfma16_bf16(a[i].lo, b[j].hi, c);   hook(s0 + 0);  RG_PIN();
+            c = mfma16_bf16(a[i].hi, b[j].lo, c);   hook(s0 + 1);  RG_PIN();
+            c = mfma16_bf16(a[i].mid, b[j].mid, c); hook(s0 + 2);  RG_PIN();
+            c = mfma16_bf16(a[i].mid, b[j].hi, c);  hook(s0 + 3);  RG_PIN();
+            c = mfma16_bf16(a[i].hi, b[j].mid, c);  hook(s0 + 4);  RG_PIN();
+            c = mfma16_bf16(a[i].hi, b[j].hi, c);   hook(s0 + 5);  RG_PIN();
+        }
+}
+
+template <typename T, typename LA, typename LB, int S, typename Load, typename Stage>
+__device__ __forceinline__ void pl_mainloop16(const unsigned (&fa)[2], const unsigned (&fb)[2], int kt_begin, int kt_end,
+                                              floatx4 (&acc)[2 * T::TM][2 * T::TN], Load load_tile, Stage stage) {
+    constexpr int TILEB = LA::BYTES + LB::BYTES;
+    constexpr int NM = 24 * T::TM * T::TN;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+#pragma unroll
+        for (int s = 0; s < S; ++s) stage(0, s);
+    }
+    __syncthreads();
+    pl_kloop(kt_begin, kt_end, load_tile, [&](auto cur_tag, auto stage_tag) {
+        constexpr int RD = decltype(cur_tag)::value ? TILEB : 0, WR = TILEB - RD;
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        mma_pl16<T::TM, T::TN>([&](int i, int pc) { return LA::frag(fa[i & 1] + RD + pc * LA::PIECE + (i >> 1) * 2 * LA::BLK); },
+                               [&](int j, int pc) { return LB::frag(fb[j & 1] + RD + pc * LB::PIECE + (j >> 1) * 2 * LB::BLK); }, acc,
+                               [&](int slot) {
+                                   if (STAGE) {
+#pragma unroll
+                                       for (int s = pl_first_step<S, NM>(slot); s < pl_end_step<S, NM>(slot); ++s)
+                                           if (s >= 0) stage(WR, s);
+                                   }
+                               });
+    });
+}

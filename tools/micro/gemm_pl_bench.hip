@@ -170,13 +170,90 @@ __global__ __launch_bounds__(T::NT) void gemm_pl(const float* __restrict__ A, co
     }
 }
 
+
+// ---- the same pipeline on v_mfma_f32_16x16x32_bf16 with 32-deep k-tiles ----
+template <typename T>
+__global__ __launch_bounds__(T::NT) void gemm_pl16(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                   int M, int N, int K, unsigned long long* __restrict__ clk) {
+    unsigned long long c0 = 0, r0 = 0;
+    if (clk && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    constexpr int BM = T::BM, BN = T::BN, NT = T::NL;
+    using LA = PlTile32<PL_R, BM>;
+    using LB = PlTile32<PL_T, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const unsigned lds0 = (unsigned)(size_t)((lds_u8_t*)lds);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / T::WN, wn = wid % T::WN;
+    const int m_tiles = M / BM;
+    const int mt = blockIdx.x % m_tiles, nt = blockIdx.x / m_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    constexpr int NUA = BM * 8 / NT, NUB = (BN / 4) * BK32 / NT;       // float4 units per thread and 32-deep tile
+    constexpr int BROWS = NT / (BN / 4);
+    static_assert(NUA >= 1 && NUB >= 1, "loader shapes");
+    PlStager<NUA, 2> sa;
+    PlStager<NUB, 2> sb;
+    const float* ap[NUA];
+    const float* bp[NUB];
+#pragma unroll
+    for (int i = 0; i < NUA; ++i) {
+        const int v = tid + NT * i, row = v >> 3, kq = (v & 7) * 4;
+        ap[i] = A + (int64_t)(m0 + row) * K + kq;
+        sa.wr[i] = lds0 + LA::off_rk(row, kq);
+    }
+    const int vcol = tid % (BN / 4), vrow0 = tid / (BN / 4);
+#pragma unroll
+    for (int i = 0; i < NUB; ++i) {
+        bp[i] = B + (int64_t)(vrow0 + i * BROWS) * N + n0 + 4 * vcol;
+        sb.wr[i] = lds0 + LA::BYTES + LB::off_rk(4 * vcol, vrow0 + i * BROWS);
+    }
+    float ra[4 * NUA], rb[4 * NUB];
+    floatx4 acc[2 * T::TM][2 * T::TN];
+#pragma unroll
+    for (int i = 0; i < 2 * T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * T::TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int kt) {
+#if defined(NO_GLOAD) || defined(NO_STAGE)
+        if (kt > 0) return;
+#endif
+#pragma unroll
+        for (int i = 0; i < NUA; ++i) pl_unpack4(&ra[4 * i], *reinterpret_cast<const float4*>(ap[i] + kt * BK32));
+#pragma unroll
+        for (int i = 0; i < NUB; ++i) pl_unpack4(&rb[4 * i], *reinterpret_cast<const float4*>(bp[i] + (int64_t)kt * BK32 * N));
+    };
+    constexpr int SA = decltype(sa)::STEPS, S = SA + decltype(sb)::STEPS;
+    const unsigned fa[2] = {lds0 + LA::frag_base(lane, wm * T::WTM, 0), lds0 + LA::frag_base(lane, wm * T::WTM, 1)};
+    const unsigned fb[2] = {lds0 + LA::BYTES + LB::frag_base(lane, wn * T::WTN, 0), lds0 + LA::BYTES + LB::frag_base(lane, wn * T::WTN, 1)};
+    pl_mainloop16<T, LA, LB, S>(fa, fb, 0, K / BK32, acc, load_tile, [&](unsigned wbuf, int s) {
+#ifdef NO_STAGE
+        if (wbuf != 0) return;
+#endif
+        if (s < SA) sa.step(s, ra, wbuf, LA::PIECE);
+        else sb.step(s - SA, rb, wbuf, LB::PIECE);
+    });
+    const int l16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 2 * T::TN; ++j)
+#pragma unroll
+        for (int i = 0; i < 2 * T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * T::WTM + i * 16 + 4 * g + r;
+                C[(int64_t)m * N + n0 + wn * T::WTN + j * 16 + l16] = acc[i][j][r];
+            }
+    if (clk && threadIdx.x == 0) {
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <typename T>
+template <typename T, bool K16 = false>
 static void run(int tpc, int K, int M) {
-    using LA = PlTile<PL_R, T::BM>;
-    using LB = PlTile<PL_T, T::BN>;
-    const size_t shmem = 2 * (size_t)(LA::BYTES + LB::BYTES);
+    const size_t shmem = K16 ? 2 * (size_t)(PlTile32<PL_R, T::BM>::BYTES + PlTile32<PL_T, T::BN>::BYTES)
+                             : 2 * (size_t)(PlTile<PL_R, T::BM>::BYTES + PlTile<PL_T, T::BN>::BYTES);
+    auto kern = K16 ? gemm_pl16<T> : gemm_pl<T>;
     const int m_tiles = M / T::BM;
     const int n_tiles = 256 * tpc / m_tiles;
     const int N = n_tiles * T::BN;
@@ -193,17 +270,17 @@ static void run(int tpc, int K, int M) {
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
-    CK(hipFuncSetAttribute((const void*)gemm_pl<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     const dim3 grid(m_tiles * n_tiles), block(T::NT);
     unsigned long long* dclk;
     CK(hipMalloc(&dclk, (size_t)grid.x * 16));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_pl<T>, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_pl<T>, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -211,8 +288,8 @@ static void run(int tpc, int K, int M) {
     ms /= reps;
     const double flop = 2.0 * M * (double)N * K;
     // clock: after ~reps launches of load, one more launch with stamps (the producer waves return early: thread 0 is a consumer)
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(gemm_pl<T>, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(gemm_pl<T>, grid, block, shmem, 0, dA, dB, dC, M, N, K, dclk);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, K, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, K, dclk);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> hclk((size_t)grid.x * 2);
     CK(hipMemcpy(hclk.data(), dclk, hclk.size() * 8, hipMemcpyDeviceToHost));
@@ -231,9 +308,9 @@ static void run(int tpc, int K, int M) {
         for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)m * lda + k] * hB[(size_t)k * N + n];
         maxerr = fmax(maxerr, fabs(ref - hC[(size_t)m * N + n]));
     }
-    printf("tile %dx%d waves %d  M %d N %d K %d  WGs %d (%d/CU)  lds %zu B: %.3f ms  %.1f TFLOP/s  clock %.2f GHz  WG %.0f cyc = %.0f per k-tile  (MFMA-bound: %d per k-tile)  maxerr %.2e\n",
-           T::BM, T::BN, T::NT / 64, M, N, K, m_tiles * n_tiles, tpc, shmem, ms, flop / ms * 1e-9, clk_ghz, wg_cycles, wg_cycles / (K / BK),
-           6 * T::TM * T::TN * 32, maxerr);
+    printf("%stile %dx%d waves %d  M %d N %d K %d  WGs %d (%d/CU)  lds %zu B: %.3f ms  %.1f TFLOP/s  clock %.2f GHz  WG %.0f cyc = %.0f per k-tile  (MFMA-bound: %d per k-tile)  maxerr %.2e\n",
+           K16 ? "16x16x32 " : "", T::BM, T::BN, T::NT / 64, M, N, K, m_tiles * n_tiles, tpc, shmem, ms, flop / ms * 1e-9, clk_ghz, wg_cycles, wg_cycles / (K / BK),
+           6 * T::TM * T::TN * 32 * (K16 ? 2 : 1), maxerr);
     CK(hipFree(dclk));
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
 }
@@ -250,5 +327,11 @@ int main(int argc, char** argv) {
     else if (tile == 4) run<Tile<128, 128, 2, 2, true>>(tpc, K, M);      // 4 consumer + 4 producer waves
     else if (tile == 5) run<Tile<256, 128, 4, 2, true>>(tpc, K, M);      // 8 + 8
     else if (tile == 6) run<Tile<128, 256, 2, 2, true>>(tpc, K, M);      // 4 + 4, 64 x 128 wave tiles
+    else if (tile == 7) run<Tile<128, 128, 2, 2>, true>(tpc, K, M);      // v_mfma_f32_16x16x32_bf16, 32-deep k-tiles
+    else if (tile == 8) run<Tile<256, 128, 4, 2>, true>(tpc, K, M);
+    else if (tile == 9) run<Tile<128, 128, 4, 2>, true>(tpc, K, M);      // 8 waves on the 128 x 128 tile (32 x 64 wave tiles)
+    else if (tile == 10) run<Tile<128, 128, 2, 4>, true>(tpc, K, M);     // 64 x 32 wave tiles
+    else if (tile == 11) run<Tile<128, 128, 4, 2>>(tpc, K, M);           // 8 waves, 32x32x16
+    else if (tile == 12) run<Tile<128, 256, 2, 4>, true>(tpc, K, M);
     return 0;
 }
