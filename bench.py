@@ -155,9 +155,11 @@ class Workload(object):
     dtype = "f32"
     peak = SPLIT_BF16_PEAK_TFLOPS     # 2500 / 6: six v_mfma_f32_32x32x16_bf16 products per fp32 product
     conv_families = ("conv_fwd", "conv_dgrad", "conv_wgrad")
-    kernel_note = ("conv implicit-GEMM family (conv_fwd/dgrad/wgrad_kernel, conv3x3_halo_kernel): fp32 in / fp32 out, every operand "
-                   "split exactly into 3 bf16 pieces, 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 "
-                   "accumulation (dropped terms <= 2^-23 per product: fp32-grade, tests at the round-2 2e-5 bounds)")
+    kernel_note = ("conv implicit-GEMM family (conv_fwd/dgrad/wgrad_kernel and their bf16-plane twins conv_*_pl_kernel — the faster of "
+                   "the two is measured once per geometry —, conv3x3_halo_kernel): fp32 in / fp32 out, every operand split exactly "
+                   "into 3 bf16 pieces, 6 of the 9 partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dropped "
+                   "terms <= 2^-23 per product: fp32-grade, tests at the round-2 2e-5 bounds); peak = 2500 / 6 at the nominal 2.4 GHz "
+                   "(the chip holds 1.4-1.6 GHz under this load: profiles/r04_micro_gemm_pl.txt, r04_mfma_shape.txt)")
     mfma_products = 6                 # bf16 matrix products issued per algorithmic fp32 product
     launch_note = "eager (one hipLaunchKernel per kernel, issued through the C ABI)"
     capture_steps = 0
@@ -410,10 +412,10 @@ WORKLOADS = {w.key: w for w in (FDGANStep, CCStep, Joint4a, Joint4b, DPTNStep)}
 
 # ---------------------------------------------------------------------------------------------------------------------
 def pmc_traffic(key, launches_per_step):
-    """HBM bytes per conv launch from the committed PMC passes (profiles/r03_pmc_traffic.json, else the round-2 file; produced on the GPU box by
+    """HBM bytes per conv launch from the committed PMC passes (profiles/r04_pmc_traffic.json, else an earlier round's; produced on the GPU box by
     tools/prof_summary.py + tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     script).  PMC counters cannot be read from inside the process, so the figure is not live; None if absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:
