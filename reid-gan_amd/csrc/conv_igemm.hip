@@ -2269,6 +2269,34 @@ static bool tune_enabled() {
 typedef std::array<int, 16> TuneKey;
 static std::map<TuneKey, int> g_tune;
 static std::mutex g_tune_mu;
+// RG_CONV_TUNE_CACHE=<file>: measured choices are appended to the file (one line of 17 integers per geometry) and loaded from it by
+// the next process, which then measures only what it has not seen — profiling runs (no measuring launches inside the trace) and
+// runs that must repeat another process's kernels bit for bit use it
+static void tune_cache_load_locked() {
+    static bool loaded = false;
+    if (loaded) return;
+    loaded = true;
+    const char* path = getenv("RG_CONV_TUNE_CACHE");
+    FILE* f = path ? fopen(path, "r") : nullptr;
+    if (!f) return;
+    TuneKey k;
+    int choice;
+    for (;;) {
+        bool ok = true;
+        for (int i = 0; i < 16 && ok; ++i) ok = fscanf(f, "%d", &k[i]) == 1;
+        if (!ok || fscanf(f, "%d", &choice) != 1) break;
+        g_tune[k] = choice ? 1 : 0;
+    }
+    fclose(f);
+}
+static void tune_cache_append_locked(const TuneKey& k, int choice) {
+    const char* path = getenv("RG_CONV_TUNE_CACHE");
+    FILE* f = path ? fopen(path, "a") : nullptr;
+    if (!f) return;
+    for (int i = 0; i < 16; ++i) fprintf(f, "%d ", k[i]);
+    fprintf(f, "%d\n", choice);
+    fclose(f);
+}
 
 // run(0): round-3 kernel, run(1): plane path (each: the kernel launch only; split-K finishers follow the choice).  Returns the
 // implementation that ran LAST (= the chosen one).
@@ -2277,6 +2305,7 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, R
     if (planes_enabled(family_bit)) { run(1); return 1; }
     if (!tune_enabled()) { run(0); return 0; }
     std::lock_guard<std::mutex> lock(g_tune_mu);
+    tune_cache_load_locked();
     auto it = g_tune.find(key);
     if (it != g_tune.end()) { run(it->second); return it->second; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -2307,6 +2336,7 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, R
     }
     const int choice = t[1] < 0.97f * t[0] ? 1 : 0;
     g_tune[key] = choice;
+    tune_cache_append_locked(key, choice);
     if (choice == 0) run(0);          // the plane path ran last: the result must come from the chosen kernel
     return choice;
 }
