@@ -153,6 +153,11 @@ def _tb_and_grads(net, tape, dys, need, params):
     return dxs, grads, assign
 
 
+def _grad_pattern(params):
+    """which parameters already hold a gradient (assign-or-accumulate state of the whole set, not of params[0] alone)"""
+    return tuple(p.grad is None for p in params) if params else None
+
+
 class _Sentinel(object):
     """frees the record when the autograd node of ITS use dies without a backward (outputs dropped, graph never differentiated);
     a node of an earlier use that is collected late (its outputs were still referenced) must not free the current use"""
@@ -186,16 +191,37 @@ class _GraphedFn(torch.autograd.Function):
             if rec.bwd is None:
                 rec.static_dys = [None if d is None else d.detach().clone() for d in dys]
                 rec.dy_none = none_pat
-                rec.bwd_first = params[0].grad is None if params else None
+                rec.bwd_first = _grad_pattern(params)
                 g = torch.cuda.CUDAGraph()
-                with _capture_mode():
-                    with torch.cuda.graph(g, pool=rec.pool):
-                        dxs, grads, assign = _tb_and_grads(net, rec.tape, rec.static_dys, need, params)
+                stack0 = list(rec.tape.stack)             # an aborted capture has popped (and recorded) without executing anything
+                try:
+                    with _capture_mode():
+                        with torch.cuda.graph(g, pool=rec.pool):
+                            dxs, grads, assign = _tb_and_grads(net, rec.tape, rec.static_dys, need, params)
+                except Exception as e:
+                    # a backward program that cannot be captured: run THIS backward eagerly over the record's tape (the forward
+                    # replay produced its saved activations for real) and retire the record; the key runs eagerly from now on
+                    import warnings
+                    warnings.warn("rg_hip.netgraph: the backward program of %s is not capturable (%s: %s); running it eagerly"
+                                  % (type(net).__name__, type(e).__name__, str(e)[:200]))
+                    torch.cuda.synchronize()
+                    rec.dead = True
+                    for ent in (net.__dict__.get("_rg_graphs") or {}).values():
+                        if rec in ent["records"]:
+                            ent["bad"] = True
+                    rec.tape.stack[:] = stack0
+                    rec.tape.grads = {}
+                    dxs, grads, assign = _tb_and_grads(net, rec.tape, list(dys), need, params)
+                    rec.tape = None
+                    hook = getattr(net, "_rg_after_backward", None)
+                    if hook is not None and params:
+                        hook()
+                    return (None, None, None) + tuple(d if (d is not None and n) else None for d, n in zip(dxs, need)) + tuple(grads)
                 rec.bwd, rec.dxs, rec.extra_grads, rec.assign = g, dxs, grads, assign
                 rec.tape = None
                 g.replay()
             else:
-                if none_pat != rec.dy_none or (params[0].grad is None if params else None) != rec.bwd_first:
+                if none_pat != rec.dy_none or _grad_pattern(params) != rec.bwd_first:
                     raise RuntimeError("rg_hip.netgraph: the pattern of output gradients / the accumulate-or-assign state of the "
                                        "parameter gradients changed between steps; set net._rg_graph = False for this network")
                 for s, d in zip(rec.static_dys, dys):
@@ -209,8 +235,10 @@ class _GraphedFn(torch.autograd.Function):
         hook = getattr(net, "_rg_after_backward", None)
         if hook is not None and params:
             hook()
-        dxs = tuple(d.detach() if (d is not None and n) else None for d, n in zip(rec.dxs, need))
-        grads = tuple(None if g is None else g.detach() for g in rec.extra_grads)
+        # gradients of leaf inputs and of parameters outside an optimizer arena are handed to autograd, which may keep the tensor
+        # (AccumulateGrad steals it): they must not alias the graph's static buffers, which the next replay overwrites
+        dxs = tuple(d.detach().clone() if (d is not None and n) else None for d, n in zip(rec.dxs, need))
+        grads = tuple(None if g is None else g.detach().clone() for g in rec.extra_grads)
         return (None, None, None) + dxs + grads
 
 

@@ -30,6 +30,18 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(d)
 
 
+def _bind_device(t):
+    """the process's GPU is the device of the FIRST tensor an op sees (not whatever torch's current device happened to be when the
+    first op ran: a rank that touches an op before torch.cuda.set_device(local_rank) must not launch on device 0's stream handle
+    forever after); tensors of another GPU are refused — one process drives one GPU"""
+    i = t.device.index
+    if _DEV[0] is None:
+        _DEV[0] = i
+    elif i != _DEV[0]:
+        raise RuntimeError("rg_hip: tensor on cuda:%d, but this process has been launching on cuda:%d (one process drives one GPU; "
+                           "call torch.cuda.set_device(local_rank) before building the networks)" % (i, _DEV[0]))
+
+
 def _chk(t, name="tensor", dtype=torch.float32):
     if t is None:
         return None
@@ -38,6 +50,8 @@ def _chk(t, name="tensor", dtype=torch.float32):
                            % (name, t.device))
     if t.dtype != dtype:
         raise TypeError("rg_hip: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.device.index != _DEV[0]:
+        _bind_device(t)
     if not t.is_contiguous() or (t.data_ptr() & 15):
         t = t.contiguous()
         if t.data_ptr() & 15:

@@ -169,3 +169,44 @@ def test_uncapturable_network_falls_back_to_eager_with_fresh_caches(dev):
     assert any("not capturable" in str(w.message) for w in caught)
     assert all(rec == 0 and not ok for _, rec, ok in NG.stats(ng).values())
     assert int(ng.bn.num_batches_tracked) == int(ne.bn.num_batches_tracked)
+
+
+def test_uncapturable_backward_falls_back_to_eager(dev):
+    """forward program captured, backward program not capturable (host read-back in tb): that backward runs eagerly over the record's
+    tape, the record is retired and the key stays eager — same numbers as a twin that never captures"""
+    import warnings
+    from rg_hip import nn as rnn, netgraph as NG
+    from rg_hip.tape import RGModule
+
+    class Net(RGModule):
+        def __init__(self):
+            super(Net, self).__init__()
+            self.c1 = rnn.Conv2d(16, 16, 3, 1, 1)
+            self.c2 = rnn.Conv2d(16, 8, 3, 1, 1)
+
+        def tf(self, tape, x):
+            return self.c2.tf(tape, self.c1.tf(tape, x, act=rnn.ACT_RELU))
+
+        def tb(self, tape, dy, need_dx=True):
+            float(dy[0, 0, 0, 0])                         # host read-back: illegal inside a stream capture
+            return self.c1.tb(tape, self.c2.tb(tape, dy), need_dx=need_dx)
+
+    torch.manual_seed(5)
+    ng, ne = Net().to(dev), Net().to(dev)
+    ne.load_state_dict(ng.state_dict())
+    ng.__dict__["_rg_graph"] = True
+    og, oe = torch.optim.SGD(ng.parameters(), lr=0.01), torch.optim.SGD(ne.parameters(), lr=0.01)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for it in range(NG.WARMUP + 4):
+            x = torch.randn(4, 16, 16, 8, device=dev, generator=torch.Generator(device=dev).manual_seed(70 + it)).requires_grad_(True)
+            x2 = x.detach().clone().requires_grad_(True)
+            for net, opt, xi in ((ng, og, x), (ne, oe, x2)):
+                opt.zero_grad()
+                net(xi).pow(2).mean().backward()
+                opt.step()
+            assert torch.equal(x.grad, x2.grad), it
+            for a, b in zip(ng.parameters(), ne.parameters()):
+                assert torch.isfinite(a).all() and torch.equal(a, b), it
+    assert any("backward program" in str(w.message) and "not capturable" in str(w.message) for w in caught)
+    assert all(not ok for _, _, ok in NG.stats(ng).values())
