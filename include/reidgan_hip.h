@@ -97,7 +97,8 @@ int rg_weights_to_krsc_multi(const void* table, int count, int total_blocks, rg_
 int rg_conv_set_force(int tile, int splits);
 /* development knob: bit mask of the conv kernel families that run on the bf16-plane operand path of csrc/conv_planes.h (operands
  * split into their bf16 pieces once, on the way into LDS) instead of the default kernels: 1 forward, 2 data gradient, 4 weight
- * gradient (same as RG_CONV_PL); identical results up to fp32 summation order.  Returns the previous mask. */
+ * gradient, 8: with a family bit, the eight-wave form of the 128 x 128 tile (same as RG_CONV_PL); identical results up to fp32
+ * summation order.  Returns the previous mask. */
 int rg_conv_set_planes(int mask);
 /* The generic fwd / dgrad / wgrad kernels exist in two implementations (default kernels and the plane path above); unless one is
  * forced (rg_conv_set_planes, RG_CONV_TUNE=0) the first call of a geometry outside a stream capture times both on the launch

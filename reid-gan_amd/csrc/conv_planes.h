@@ -26,8 +26,9 @@
 // still has one wave-uniform k and lanes along the pixels).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int BMODE, bool AVEC>
-__global__ __launch_bounds__(NT) void conv_fwd_pl_kernel(const ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_fwd_pl_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
+    constexpr int NTH = 64 * WM * WN;                       // 4 waves (the tiles of RG_TILE_SWITCH) or 8 (128 x 128 as 4 x 2 waves)
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     using LA = PlTile<PL_R, BM>;
     using LB = PlTile<BMODE == 2 ? PL_T : PL_R, BN>;
@@ -46,9 +47,9 @@ __global__ __launch_bounds__(NT) void conv_fwd_pl_kernel(const ConvP p) {
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
 
     // ---- A operand (filters) ----
-    constexpr int NAV = (BM * 4 + NT - 1) / NT;            // AVEC: float4 per thread and tile
-    constexpr bool AFULL = BM * 4 >= NT;                   // every thread stages a float4
-    constexpr int EA = BM * BK / NT;                       // scalar: consecutive k per thread (thread = row tid % BM, chunk tid / BM)
+    constexpr int NAV = (BM * 4 + NTH - 1) / NTH;            // AVEC: float4 per thread and tile
+    constexpr bool AFULL = BM * 4 >= NTH;                   // every thread stages a float4
+    constexpr int EA = BM * BK / NTH;                       // scalar: consecutive k per thread (thread = row tid % BM, chunk tid / BM)
     static_assert(AVEC || EA >= 2, "scalar filter chunk of at least one pair");
     constexpr int NUA = AVEC ? NAV : 1, SPA = AVEC ? 2 : EA / 2;      // staged units and element pairs per unit
     unsigned aoff[NUA];                                    // global byte offset at k-tile 0, or OOB
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_pl_kernel(const ConvP p) {
     if (AVEC) {
 #pragma unroll
         for (int i = 0; i < NAV; ++i) {
-            const int v = tid + NT * i;
+            const int v = tid + NTH * i;
             const int row = v >> 2;
             akq[i] = (v & 3) * 4;
             aact = AFULL || v < BM * 4;
@@ -74,10 +75,10 @@ __global__ __launch_bounds__(NT) void conv_fwd_pl_kernel(const ConvP p) {
 
     // ---- B operand (pixels) ----
     constexpr int BV = BN / 4;
-    constexpr int BVSTEP = NT / BV;
-    constexpr int BVCNT = BV * BK / NT;
-    static_assert(BV * BK % NT == 0, "whole float4 passes");
-    constexpr int EB = BN * BK / NT;                       // gather: consecutive k per thread (thread = column tid % BN, chunk tid / BN)
+    constexpr int BVSTEP = NTH / BV;
+    constexpr int BVCNT = BV * BK / NTH;
+    static_assert(BV * BK % NTH == 0, "whole float4 passes");
+    constexpr int EB = BN * BK / NTH;                       // gather: consecutive k per thread (thread = column tid % BN, chunk tid / BN)
     constexpr int EBU = EB > 8 ? 8 : EB;                   // .. per staged unit (one 16-byte store per piece at most)
     constexpr int NUB = BMODE == 2 ? BVCNT : EB / EBU, SPB = BMODE == 2 ? 2 : EBU / 2;
     const int vcol = tid % BV, vrow0 = tid / BV;
@@ -236,8 +237,9 @@ __global__ __launch_bounds__(NT) void conv_fwd_pl_kernel(const ConvP p) {
 // indices, each load instruction one wave-uniform k with lanes along the pixels) -> PL_R.
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_pl_kernel(const DgradP dp) {
     using T = Tile<BM, BN, WM, WN>;
+    constexpr int NTH = 64 * WM * WN;                       // 4 waves (the tiles of RG_TILE_SWITCH) or 8 (128 x 128 as 4 x 2 waves)
     static_assert(BN >= 64, "the gather loader needs a wave-uniform k");
     using LA = PlTile<MODE == 0 ? PL_R : PL_T, BM>;
     using LB = PlTile<MODE == 2 ? PL_T : PL_R, BN>;
@@ -264,9 +266,9 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rdy = make_rsrc(p.x, p.x_bytes);
 
     // ---- B operand (dy) ----
-    constexpr int BV = BN / 4, BVSTEP = NT / BV, BVCNT = BV * BK / NT;
-    static_assert(BV * BK % NT == 0, "whole float4 passes");
-    constexpr int EB = BN * BK / NT, EBU = EB > 8 ? 8 : EB;
+    constexpr int BV = BN / 4, BVSTEP = NTH / BV, BVCNT = BV * BK / NTH;
+    static_assert(BV * BK % NTH == 0, "whole float4 passes");
+    constexpr int EB = BN * BK / NTH, EBU = EB > 8 ? 8 : EB;
     constexpr int NUB = MODE == 2 ? BVCNT : EB / EBU;
     PlStager<NUB, MODE == 2 ? 2 : EBU / 2> sb;
     const int vcol = tid % BV, vrow0 = tid / BV;
@@ -301,10 +303,10 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
     }
 
     // ---- A operand (filters), GEMM row m = input channel c ----
-    constexpr int EA = BM * BK / NT;                       // MODE 0: consecutive k per thread (thread = row tid % BM, chunk tid / BM)
+    constexpr int EA = BM * BK / NTH;                       // MODE 0: consecutive k per thread (thread = row tid % BM, chunk tid / BM)
     static_assert(MODE != 0 || EA >= 2, "scalar filter chunk of at least one pair");
-    constexpr int AV = BM / 4, AVSTEP = NT / AV, AVCNT = (AV * BK + NT - 1) / NT;
-    constexpr bool AFULL = AV * BK >= NT;                  // every thread stages a float4 (BM >= 64)
+    constexpr int AV = BM / 4, AVSTEP = NTH / AV, AVCNT = (AV * BK + NTH - 1) / NTH;
+    constexpr bool AFULL = AV * BK >= NTH;                  // every thread stages a float4 (BM >= 64)
     constexpr int NUA = MODE == 0 ? 1 : AVCNT;
     PlStager<NUA, MODE == 0 ? EA / 2 : 2> sa;
     const int arow = tid % BM, akc = tid / BM;
@@ -436,8 +438,9 @@ __global__ __launch_bounds__(NT) void conv_dgrad_pl_kernel(const DgradP dp) {
 // thread = one GEMM row / column, E consecutive output pixels (the pixel decode is wave-uniform: scalar unit).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool VEC, bool VECA>
-__global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_pl_kernel(const ConvP p) {
     using T = Tile<BM, BN, WM, WN>;
+    constexpr int NTH = 64 * WM * WN;                       // 4 waves (the tiles of RG_TILE_SWITCH) or 8 (128 x 128 as 4 x 2 waves)
     static_assert(BN >= 64, "the gather loader needs a wave-uniform pixel chunk");
     using LA = PlTile<PL_R, BM>;
     using LB = PlTile<PL_R, BN>;
@@ -466,9 +469,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
     const bool nopad = p.PH == 0 && p.PW == 0 && (p.P - 1) * p.SH + p.KH <= p.H && (p.Q - 1) * p.SW + p.KW <= p.W;
 
     // ---- A operand (dy): rows = output channels ----
-    constexpr int AVN = (BM * 4 + NT - 1) / NT;            // VECA: float4 (4 consecutive pixels of one row) per thread and tile
-    constexpr bool AFULL = BM * 4 >= NT;
-    constexpr int EA = BM * BK / NT;                       // scalar: consecutive pixels per thread (thread = row tid % BM, chunk tid / BM)
+    constexpr int AVN = (BM * 4 + NTH - 1) / NTH;            // VECA: float4 (4 consecutive pixels of one row) per thread and tile
+    constexpr bool AFULL = BM * 4 >= NTH;
+    constexpr int EA = BM * BK / NTH;                       // scalar: consecutive pixels per thread (thread = row tid % BM, chunk tid / BM)
     static_assert(VECA || EA >= 2, "scalar chunk of at least one pair");
     PlStager<VECA ? AVN : 1, VECA ? 2 : EA / 2> sa;
     const int vrow = tid >> 2, vkq = (tid & 3) * 4;
@@ -478,9 +481,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
     if constexpr (VECA) {
 #pragma unroll
         for (int i = 0; i < AVN; ++i) {
-            const int m = m0 + vrow + 64 * i;
+            const int m = m0 + vrow + (NTH / 4) * i;
             avoff[i] = (aact && m < p.M) ? (unsigned)m * (unsigned)PQ * 4u : OOB;
-            sa.wr[i] = lds0 + LA::off_rk(aact ? vrow + 64 * i : 0, vkq);
+            sa.wr[i] = lds0 + LA::off_rk(aact ? vrow + (NTH / 4) * i : 0, vkq);
         }
     } else {
         avoff[0] = (m0 + arow < p.M) ? (unsigned)(m0 + arow) * (unsigned)PQ * 4u : OOB;
@@ -488,9 +491,9 @@ __global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
     }
 
     // ---- B operand (im2col of x, transposed): columns = (c, r, s) ----
-    constexpr int BVN = (BN * 4 + NT - 1) / NT;            // VEC: float4 per thread and tile
-    static_assert(BN * 4 >= NT, "every thread stages a column float4");
-    constexpr int EB = BN * BK / NT, EBU = EB > 8 ? 8 : EB;
+    constexpr int BVN = (BN * 4 + NTH - 1) / NTH;            // VEC: float4 per thread and tile
+    static_assert(BN * 4 >= NTH, "every thread stages a column float4");
+    constexpr int EB = BN * BK / NTH, EBU = EB > 8 ? 8 : EB;
     constexpr int NUB = VEC ? BVN : EB / EBU;
     PlStager<NUB, VEC ? 2 : EBU / 2> sb;
     unsigned bvoff[VEC ? BVN : 1];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
     if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < BVN; ++i) {
-            const int n = n0 + vrow + 64 * i;
+            const int n = n0 + vrow + (NTH / 4) * i;
             int c = n;
             vrr[i] = vss[i] = 0;
             if (p.wshift) {
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_pl_kernel(const ConvP p) {
                 vss[i] = rs - r * p.KW - p.PW;
             }
             bvoff[i] = n < p.Ng ? (unsigned)c * (unsigned)HW * 4u : OOB;
-            sb.wr[i] = lds0 + LA::BYTES + LB::off_rk(vrow + 64 * i, vkq);
+            sb.wr[i] = lds0 + LA::BYTES + LB::off_rk(vrow + (NTH / 4) * i, vkq);
         }
     } else {
         const int n = n0 + bcol;

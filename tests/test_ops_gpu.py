@@ -860,11 +860,17 @@ def test_batchnorm_train_single_launch(dev, shape, act):
     _close(i2, invstd, tol=1e-5, name="invstd vs bn_stats")
 
 
-PLANES_CASES = [c for c in CONV_CASES if c[4] > 4 and c[1] > 4][:28]
+PLANES_CASES = [c for c in CONV_CASES if c[4] > 4 and c[1] > 4][:28] + [
+    (16, 128, 16, 8, 256, 1, 1, 1, 0),    # 128 x 128 tiles: 1x1 (float4 both operands)
+    (16, 64, 32, 16, 128, 4, 4, 2, 1),    # 128 x 128 tiles: gather loaders, strided data gradient
+    (8, 128, 16, 16, 128, 3, 3, 2, 1),    # 3x3 / 2
+    (6, 160, 12, 10, 136, 1, 1, 1, 0),    # ragged rows / columns on the big tile
+]
 
 
+@pytest.mark.parametrize("mask", [7, 15])          # 15: the eight-wave form where the plan uses the 128 x 128 tile
 @pytest.mark.parametrize("case", PLANES_CASES)
-def test_conv_planes_kernels(dev, case):
+def test_conv_planes_kernels(dev, case, mask):
     """the bf16-plane operand path (csrc/conv_planes.h: operands split once on their way into LDS, fragments by ds_read_b128 /
     ds_read_b64_tr_b16) — not the default (it measured no faster) but kept correct: same bounds as the default
     kernels, every loader variant (float4 along k / along the rows, blocked scalar gathers, ragged tiles, split-K)"""
@@ -878,7 +884,7 @@ def test_conv_planes_kernels(dev, case):
     y_ref = F.conv2d(xd, wd, stride=s, padding=p)
     dy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(dy.double())
-    old = rglib.lib.rg_conv_set_planes(7)
+    old = rglib.lib.rg_conv_set_planes(mask)
     try:
         _close(ops.conv2d_fwd(x.to(dev), w.to(dev), s, p), y_ref, name="fwd (planes)")
         _close(ops.conv2d_dgrad(dy.to(dev), w.to(dev), (H, W), s, p), xd.grad, name="dgrad (planes)")
