@@ -2262,6 +2262,10 @@ static bool planes_enabled(int family_bit) {
     if (g_planes_mask < 0) g_planes_mask = getenv("RG_CONV_PL") ? atoi(getenv("RG_CONV_PL")) : 0;
     return (g_planes_mask & family_bit) != 0;
 }
+static bool path_tune_enabled() {
+    static const int env = getenv("RG_CONV_TUNE_PATH") ? atoi(getenv("RG_CONV_TUNE_PATH")) : 1;
+    return env != 0;
+}
 static bool tune_enabled() {
     static const int env = getenv("RG_CONV_TUNE") ? atoi(getenv("RG_CONV_TUNE")) : 1;
     return env != 0;
@@ -2312,10 +2316,17 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, i
     if (!tune_enabled()) { run(0); return 0; }
     static const int tune8 = getenv("RG_CONV_TUNE8") ? atoi(getenv("RG_CONV_TUNE8")) : 1;      // 0: the eight-wave form is not a candidate
     if (!tune8 && ncand > 2) ncand = 2;
-    std::lock_guard<std::mutex> lock(g_tune_mu);
-    tune_cache_load_locked();
-    auto it = g_tune.find(key);
-    if (it != g_tune.end() && it->second < ncand) { run(it->second); return it->second; }
+    {                                 // the lock covers the table only, never a launch: measurements may nest (path choice below)
+        std::unique_lock<std::mutex> lock(g_tune_mu);
+        tune_cache_load_locked();
+        auto it = g_tune.find(key);
+        if (it != g_tune.end() && it->second < ncand) {
+            const int c = it->second;
+            lock.unlock();
+            run(c);
+            return c;
+        }
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -2346,8 +2357,11 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, i
     float best = t[0];
     for (int c = 1; c < ncand; ++c)
         if (t[c] < 0.97f * best) { best = t[c]; choice = c; }
-    g_tune[key] = choice;
-    tune_cache_append_locked(key, choice);
+    {
+        std::lock_guard<std::mutex> lock(g_tune_mu);
+        g_tune[key] = choice;
+        tune_cache_append_locked(key, choice);
+    }
     if (choice != ncand - 1) run(choice);             // the result must come from the chosen kernel
     return choice;
 }
@@ -2565,56 +2579,82 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             return rg::check_launch("rg_conv2d_fwd(thin finish)");
         }
     }
+    // 3x3 / stride 1 / pad 1 layers: the tap-reuse kernel or the generic implicit GEMM on the (r,s)-major filters — whichever is
+    // faster for the geometry, measured once like the kernel implementations (RG_CONV_TUNE_PATH=0: always the tap-reuse kernel)
+    bool halo_ok = false;
+    HaloPlan hpl = HaloPlan();
     {
         int hpv, wh, slab;
         // (fewer than 64 output rows: the 32 x 256 tile of the generic kernel wastes less than a half-empty 64-row tile)
         if (KH == 3 && KW == 3 && SH == 1 && SW == 1 && PH == 1 && PW == 1 && C % BK == 0 && K >= 64 && w_krsc &&
             ((reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 && halo_enabled() &&
             halo_geom(H, W, &hpv, &wh, &slab)) {
-            HaloPlan hpl = halo_plan(p.M, p.Ng, C);
+            halo_ok = true;
+            hpl = halo_plan(p.M, p.Ng, C);
             const size_t need = hpl.splits > 1 ? (size_t)hpl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
             if (need > workspace_bytes || (need && !workspace)) {
                 hpl.splits = 1;
                 hpl.per = C / BK;
             }
-            p.w = w_krsc;
-            rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
-            return halo_launch<false>(p, C, H, W, hpl, workspace, stream, "rg_conv2d_fwd(3x3 tap reuse)");
         }
     }
-    const bool is1x1 = KH == 1 && KW == 1;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
-    const bool avec = (p.Kg % 4 == 0) && aligned;
-    int bmode = 0;
-    if (avec && is1x1 && SH == 1 && SW == 1 && PH == 0 && PW == 0 && ((H * W) % 4 == 0)) bmode = 2;
-    else if (avec && C % 16 == 0 && (is1x1 || (w_krsc && (reinterpret_cast<uintptr_t>(w_krsc) & 15) == 0))) {
-        bmode = 1;
-        if (!is1x1) p.w = w_krsc;
+    const ConvP p0 = p;
+    auto launch_halo = [&]() -> int {
+        ConvP ph = p0;
+        ph.w = w_krsc;
+        rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * ph.M * (double)ph.Ng * ph.Kg, ALG_BYTES);
+        return halo_launch<false>(ph, C, H, W, hpl, workspace, stream, "rg_conv2d_fwd(3x3 tap reuse)");
+    };
+    auto launch_generic = [&]() -> int {
+        p = p0;
+        const bool is1x1 = KH == 1 && KW == 1;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+        const bool avec = (p.Kg % 4 == 0) && aligned;
+        int bmode = 0;
+        if (avec && is1x1 && SH == 1 && SW == 1 && PH == 0 && PW == 0 && ((H * W) % 4 == 0)) bmode = 2;
+        else if (avec && C % 16 == 0 && (is1x1 || (w_krsc && (reinterpret_cast<uintptr_t>(w_krsc) & 15) == 0))) {
+            bmode = 1;
+            if (!is1x1) p.w = w_krsc;
+        }
+        GemmPlan pl = plan_gemm(p.M, p.Ng, p.Kg, true);
+        const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
+        if (need > workspace_bytes || (need && !workspace)) {     // no scratch given: run unsplit
+            pl.splits = 1;
+            pl.ktiles_per_split = 1 << 30;
+        }
+        p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
+        p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
+        p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
+        p.partial_bytes = (unsigned)need;
+        rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
+        const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
+        const TuneKey tk = {1, N, C, H, W, K, KH, KW, SH, SW, PH, PW, bmode * 2 + (avec ? 1 : 0), pl.tile, pl.splits,
+                            (int)(p.ep.res != nullptr) * 4 + p.ep.act};
+        choose_impl(1, tk, stream, pl.tile <= 1 ? 3 : 2, [&](int impl) {
+            if (impl == 2) {                  // eight waves: 128 x 128 as 4 x 2 waves of 32 x 64, 64 x 128 as 2 x 4 waves of 32 x 32
+                if (pl.tile == 0) { RG_FWD_PL_LAUNCH(128, 128, 4, 2); }
+                else { RG_FWD_PL_LAUNCH(64, 128, 2, 4); }
+            }
+            else if (impl) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
+            else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
+        });
+        if (pl.splits > 1) {
+            if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
+            launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
+        }
+        return rg::check_launch("rg_conv2d_fwd");
+    };
+    if (halo_ok) {
+        if (!tune_enabled() || !path_tune_enabled()) return launch_halo();
+        int st = RG_OK;
+        const TuneKey hk = {16, N, C, H, W, K, KH, KW, SH, SW, PH, PW, 0, 0, 0, (int)(p0.ep.res != nullptr) * 4 + p0.ep.act};
+        choose_impl(0, hk, stream, 2, [&](int c) {
+            const int e = c ? launch_generic() : launch_halo();
+            if (e) st = e;
+        });
+        return st;
     }
-    GemmPlan pl = plan_gemm(p.M, p.Ng, p.Kg, true);
-    const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
-    if (need > workspace_bytes || (need && !workspace)) {     // no scratch given: run unsplit
-        pl.splits = 1;
-        pl.ktiles_per_split = 1 << 30;
-    }
-    p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
-    p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
-    p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
-    p.partial_bytes = (unsigned)need;
-    rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
-    const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
-    const TuneKey tk = {1, N, C, H, W, K, KH, KW, SH, SW, PH, PW, bmode * 2 + (avec ? 1 : 0), pl.tile, pl.splits,
-                        (int)(p.ep.res != nullptr) * 4 + p.ep.act};
-    choose_impl(1, tk, stream, pl.tile == 0 ? 3 : 2, [&](int impl) {
-        if (impl == 2) { RG_FWD_PL_LAUNCH(128, 128, 4, 2); }
-        else if (impl) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
-        else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
-    });
-    if (pl.splits > 1) {
-        if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
-        launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
-    }
-    return rg::check_launch("rg_conv2d_fwd");
+    return launch_generic();
 }
 
 // development knob (tools/sweep_tiles.py): pin the planner's tile / split choice at run time; (-1, -1) releases it
@@ -2686,7 +2726,7 @@ namespace {
 int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, int N, int C, int H, int W, int K, int KH, int KW,
                int SH, int SW, int PH, int PW, int P, int Q, const float* scale, const float* shift, const float* residual,
                int act, float slope, const float* relu_mask, float* rowsum, int rowsum_cols, void* workspace,
-               size_t workspace_bytes, hipStream_t stream, int* dry) {
+               size_t workspace_bytes, hipStream_t stream, int* dry, bool allow_halo = true) {
     if (int e = validate("rg_conv2d_dgrad", N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q)) return e;
     RG_REQUIRE(dry || (dy && w && dx), "rg_conv2d_dgrad: null tensor");
     RG_REQUIRE(SH <= 2 && SW <= 2, "rg_conv2d_dgrad: stride > 2 not supported (got %d,%d)", SH, SW);
@@ -2762,7 +2802,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
         int hpv, wh, slab;
         // (a planning call has no pointers: rg_hip.ops always passes the [K][9][C] copy for such layers)
         if (one_class && KH == 3 && KW == 3 && PH == 1 && PW == 1 && P == H && Q == W && K % BK == 0 && C % 4 == 0 && C >= 64 &&
-            (dry || (wk && dy_al)) && halo_enabled() && halo_geom(H, W, &hpv, &wh, &slab)) {
+            (dry || (wk && dy_al)) && halo_enabled() && allow_halo && halo_geom(H, W, &hpv, &wh, &slab)) {
             HaloPlan hpl = halo_plan(p.M, ng_max, K);
             const size_t need = hpl.splits > 1 ? (size_t)hpl.splits * p.M * (size_t)ng_max * sizeof(float) : 0;
             if (!dry && (need > workspace_bytes || (need && !workspace))) {
@@ -2780,8 +2820,34 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
             p.w = wk;
             p.Ng = (int)ng_max;
             p.Kg = K * KH * KW;
-            rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
-            return halo_launch<true>(p, K, H, W, hpl, workspace, stream, "rg_conv2d_dgrad(3x3 tap reuse)");
+            const ConvP ph0 = p;
+            auto launch_halo = [&]() -> int {
+                ConvP ph = ph0;
+                rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
+                return halo_launch<true>(ph, K, H, W, hpl, workspace, stream, "rg_conv2d_dgrad(3x3 tap reuse)");
+            };
+            // the tap-reuse kernel and the generic kernels compete per geometry, as in the forward pass — with fused row sums only
+            // when the generic plan writes the same row-sum columns (their count is the caller's contract with the planning query:
+            // both unsplit on 128-pixel tiles with two wave columns -> the same column per (n-tile, wave column))
+            bool can_tune = tune_enabled() && path_tune_enabled();
+            if (can_tune && rowsum) {
+                int gcols = -1;
+                can_tune = dgrad_impl(nullptr, nullptr, nullptr, nullptr, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, nullptr, nullptr, nullptr,
+                                      act, slope, nullptr, nullptr, 0, nullptr, 0, nullptr, &gcols, false) == RG_OK && gcols == cols;
+            }
+            if (can_tune) {
+                int st = RG_OK;
+                const TuneKey hk = {32, N, C, H, W, K, KH, KW, SH, SW, PH, PW, 0, 0, 0,
+                                    (int)(residual != nullptr) * 16 + (int)(relu_mask != nullptr) * 8 + (int)(rowsum != nullptr) * 4 + act};
+                choose_impl(0, hk, stream, 2, [&](int c) {
+                    const int e = c ? dgrad_impl(dy, w, w_krsc, dx, N, C, H, W, K, KH, KW, SH, SW, PH, PW, P, Q, scale, shift, residual, act,
+                                                 slope, relu_mask, rowsum, rowsum_cols, workspace, workspace_bytes, stream, nullptr, false)
+                                    : launch_halo();
+                    if (e) st = e;
+                });
+                return st;
+            }
+            return launch_halo();
         }
     }
     // strided classes: only classes that have filter taps do MFMA work (a 1x1 / stride-2 layer has ONE such class, the
@@ -2848,9 +2914,11 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     static const int dma_env = getenv("RG_CONV_DMA") ? atoi(getenv("RG_CONV_DMA")) : 1;
     const TuneKey tk = {2, N, C, H, W, K, KH, KW, SH, SW, PH, PW, mode, pl.tile, pl.splits,
                         (int)(p.ep.res != nullptr) * 16 + (int)(p.ep.mask != nullptr) * 8 + (int)(p.ep.rowsum != nullptr) * 4 + p.ep.act};
-    choose_impl(2, tk, stream, pl.tile == 0 ? 3 : 2, [&](int impl) {
+    // (the 64 x 128 eight-wave form has four wave columns: not with fused row sums, whose column count the caller sized for two)
+    choose_impl(2, tk, stream, (pl.tile == 0 || (pl.tile == 1 && !p.ep.rowsum)) ? 3 : 2, [&](int impl) {
         if (impl == 2) {
-            RG_DGRAD_PL_LAUNCH(128, 128, 4, 2);
+            if (pl.tile == 0) { RG_DGRAD_PL_LAUNCH(128, 128, 4, 2); }
+            else { RG_DGRAD_PL_LAUNCH(64, 128, 2, 4); }
         } else if (impl) {
             RG_TILE_SWITCH(pl.tile, RG_DGRAD_PL_LAUNCH);
         } else if (mode == 2 && dma_env && (pl.tile == 0 || pl.tile == 1) && C % 4 == 0) {

@@ -590,18 +590,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_pl_kernel(const ConvP
                 for (int i = 0; i < BVN; ++i) pl_unpack4(&rb[4 * i], bload4(rx, ((bb | bvoff[i]) & OOB) ? OOB : bb + bvoff[i]));
             }
         } else {
+            // wave-uniform pixel decode on the scalar unit: two divisions for the first pixel of the chunk, increments with carry for
+            // the others (the chunk's pixels are consecutive output pixels)
+            const int g0 = kt * BK + bkc * EB;
+            int img = fdiv(g0 < p.Kg ? g0 : 0, p.d_pq);
+            int pp = fdiv(g0 < p.Kg ? g0 - img * PQ : 0, p.d_q);
+            int qq = (g0 < p.Kg ? g0 - img * PQ : 0) - pp * p.Q;
 #pragma unroll
             for (int e = 0; e < EB; ++e) {
-                const int g = kt * BK + bkc * EB + e;            // wave-uniform: pixel decode on the scalar unit
-                const bool gvalid = g < p.Kg;
-                const int img = gvalid ? fdiv(g, p.d_pq) : 0;
-                const int pq = g - img * PQ;
-                const int pp = fdiv(gvalid ? pq : 0, p.d_q);
-                const int qq = pq - pp * p.Q;
+                const bool gvalid = g0 + e < p.Kg;
                 const int h0 = pp * p.SH - p.PH, w0 = qq * p.SW - p.PW;
                 const int xb = img * p.C * HW + h0 * p.W + w0;   // element index of (img, 0, h0, w0); may sit in the padding
                 const bool ok = gvalid && cvalid && (nopad || ((unsigned)(h0 + cr) < (unsigned)p.H && (unsigned)(w0 + cs) < (unsigned)p.W));
                 rb[e] = bload(rx, ok ? (unsigned)(xb + coff) * 4u : OOB);
+                if (++qq == p.Q) {
+                    qq = 0;
+                    if (++pp == p.P) { pp = 0; ++img; }
+                }
             }
         }
     };
