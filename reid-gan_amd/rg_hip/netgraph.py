@@ -49,6 +49,14 @@ def _bn_layers(net):
     return [m for m in net.modules() if isinstance(m, _BatchNorm)]
 
 
+# hipStreamCaptureModeThreadLocal: only the CAPTURING thread is held to the capture rules.  With the default ("global") a HIP call
+# from any other thread while a capture is open invalidates the capture — and the process group's watchdog thread polls the events
+# of in-flight collectives (hipEventQuery) every few milliseconds: a gradient all-reduce still in flight when a network's program is
+# captured (the joint step launches the encoder's and the discriminators' reductions before the generator's backward) then aborts
+# the capture and, through the watchdog's own exception, the process.
+_CAPTURE_MODE = "thread_local"
+
+
 def graphable(net):
     """no active Dropout (it draws a seed from the host generator per call; a replay would repeat the captured one)"""
     from .nn import Dropout
@@ -97,7 +105,7 @@ def _capture_forward(net, xs, params):
     g = torch.cuda.CUDAGraph()
     try:
         with _capture_mode():
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 outs = net.tf(rec.tape, *rec.static_in)
     except Exception:
         # the aborted program's Python side effects must not survive it: none of its kernels ran.  Cache keys are not stamped while
@@ -196,7 +204,7 @@ class _GraphedFn(torch.autograd.Function):
                 stack0 = list(rec.tape.stack)             # an aborted capture has popped (and recorded) without executing anything
                 try:
                     with _capture_mode():
-                        with torch.cuda.graph(g, pool=rec.pool):
+                        with torch.cuda.graph(g, pool=rec.pool, capture_error_mode=_CAPTURE_MODE):
                             dxs, grads, assign = _tb_and_grads(net, rec.tape, rec.static_dys, need, params)
                 except Exception as e:
                     # a backward program that cannot be captured: run THIS backward eagerly over the record's tape (the forward

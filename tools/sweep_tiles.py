@@ -40,7 +40,7 @@ for name, cnt, C, H, W, K, k, s, p in shapes:
         base = t(fn)
         best, bcfg = base, "plan"
         for tile in (0, 1, 2):
-            for sp in ((1, 2, 4, 8) if (kind == "fwd" or s == 1) else (1,)):
+            for sp in (1, 2, 3, 4, 6, 8):
                 lib.rg_conv_set_force(tile, sp)
                 ops._ws_sizes.clear()
                 try:
