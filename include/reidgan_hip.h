@@ -12,7 +12,7 @@
  *   - returns 0 (RG_OK) or a negative status; rg_last_error() gives the message (thread local);
  *   - plain pointers to DEVICE memory and sizes; tensors are contiguous fp32 NCHW, labels int64;
  *   - asynchronous on `stream`; never allocates, frees or synchronises (rg_profile_collect excepted; the first call of a
- *     convolution geometry outside a stream capture waits once for a two-kernel timing on `stream`: rg_conv_tune_stats);
+ *     convolution geometry outside a stream capture waits once for a timing of its candidate kernels on `stream`: rg_conv_tune_stats);
  *   - scratch comes from the caller: `workspace`/`workspace_bytes`, sized by the *_workspace query;
  *   - pointers must be 16-byte aligned (torch allocations are).
  */
@@ -102,8 +102,9 @@ int rg_conv_set_force(int tile, int splits);
 int rg_conv_set_planes(int mask);
 /* The generic fwd / dgrad / wgrad kernels exist in two implementations (default kernels and the plane path above); unless one is
  * forced (rg_conv_set_planes, RG_CONV_TUNE=0) the first call of a geometry outside a stream capture times both on the launch
- * stream and the faster serves that geometry from then on (the first call's output already comes from it).  Returns the number of
- * geometries measured so far; out[0] / out[1] (int[2], may be NULL): how many chose the default kernels / the plane path. */
+ * stream and the faster serves that geometry from then on (the first call's output already comes from it); the tile / split-K plan
+ * of a forward geometry and the tap-reuse-vs-generic path of a 3x3 layer are chosen the same way.  Returns the number of choices
+ * measured so far; out[0] / out[1] (int[2], may be NULL): how many kernel choices went to the default kernels / the plane path. */
 int rg_conv_tune_stats(int* out);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
@@ -170,6 +171,9 @@ int rg_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, f
  * per sample. */
 int rg_pair_cat(const float* a, const float* b, const int64_t* take_a, float* out, int B, int64_t per, rg_stream_t stream);
 int rg_fill(float* y, int64_t n, float v, rg_stream_t stream);
+/* one idle wave for `us` microseconds (1..100000) on `stream`: the probe rg_hip.ops.concurrent_stream uses to find streams that do
+ * not share a hardware queue (no reference counterpart: the reference is single-stream) */
+int rg_spin_us(int us, rg_stream_t stream);
 /* (x1-x2)^2 of EltwiseSubEmbed, FD/reid/models/embedding.py:26-31 */
 int rg_sub_square_fwd(const float* a, const float* b, float* y, int64_t n, rg_stream_t stream);
 int rg_sub_square_bwd(const float* a, const float* b, const float* dy, float* da, float* db, int64_t n,

@@ -2214,6 +2214,60 @@ static GemmPlan plan_gemm(int M, int64_t Ng, int64_t Kg, bool allow_split) {
     return pl;
 }
 
+// The cost model above was fitted to the round-1..3 kernels; against the eight-wave plane kernels it is off by one tile size or
+// one split step on about a third of the ResNet geometries (tools/sweep_tiles.py, round 4: forward -6 %, data gradient -4 % with the
+// best forced plan per layer).  So the PLAN is a measured choice too: the model's plan first, then every other tile of the shape
+// class with 1 / 2 / 3 / 4 / 6 / 8 splits that keeps >= 4 k-tiles per split and <= 1 536 workgroups; an alternative has to beat the
+// model's plan by 3 % (choose_impl).  RG_CONV_TUNE_PLAN=0 / RG_CONV_TUNE=0 / a forced plan: the model's plan only.
+static bool tune_enabled();
+static bool plan_tune_enabled() {
+    static const int env = getenv("RG_CONV_TUNE_PLAN") ? atoi(getenv("RG_CONV_TUNE_PLAN")) : 1;
+    return env != 0;
+}
+static GemmPlan make_plan(int M, int64_t Ng, int64_t nk, int tile, int splits) {
+    GemmPlan pl;
+    pl.tile = tile;
+    pl.m_tiles = rg::cdiv(M, kTileBM[tile]);
+    pl.n_tiles = (int)rg::cdiv64(Ng, kTileBN[tile]);
+    pl.ktiles_per_split = (int)rg::cdiv64(nk, splits);
+    pl.splits = (int)rg::cdiv64(nk, pl.ktiles_per_split);
+    return pl;
+}
+static int plan_candidates(int M, int64_t Ng, int64_t Kg, GemmPlan* out, int max_out, bool only_bn128 = false) {
+    out[0] = plan_gemm(M, Ng, Kg, true);
+    int n = 1;
+    if (g_force_tile >= 0 || g_force_splits >= 1 || !plan_tune_enabled() || !tune_enabled() || M <= 32) return n;
+    const int64_t nk = rg::cdiv64(Kg > 0 ? Kg : 1, BK);
+    int tiles[3], nt = 0;
+    if (Ng >= 128) {
+        if (M > 64) tiles[nt++] = 0;
+        tiles[nt++] = 1;
+    }
+    if (!only_bn128) tiles[nt++] = 2;
+    static const int ss[6] = {1, 2, 3, 4, 6, 8};
+    for (int ti = 0; ti < nt && n < max_out; ++ti)
+        for (int si = 0; si < 6 && n < max_out; ++si) {
+            const int t = tiles[ti], sp = ss[si];
+            if (only_bn128 && sp > 1) continue;
+            if (sp > 1 && (nk / sp < 4 || (int64_t)sp * M * Ng * 4 >= (1ll << 31))) continue;
+            const int64_t wgs = (int64_t)rg::cdiv(M, kTileBM[t]) * rg::cdiv64(Ng, kTileBN[t]);
+            if (sp > 1 && wgs * sp > 1536) continue;
+            const GemmPlan pl = make_plan(M, Ng, nk, t, sp);
+            bool dup = false;
+            for (int i = 0; i < n; ++i) dup = dup || (out[i].tile == pl.tile && out[i].splits == pl.splits);
+            if (!dup) out[n++] = pl;
+        }
+    return n;
+}
+static size_t plans_workspace(const GemmPlan* pl, int n, int M, int64_t Ng) {
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t b = pl[i].splits > 1 ? (size_t)pl[i].splits * M * (size_t)Ng * sizeof(float) : 0;
+        if (b > need) need = b;
+    }
+    return need;
+}
+
 static unsigned finish_grid(int64_t n) {
     int64_t g = rg::cdiv64(n, 256);
     if (g > 4096) g = 4096;
@@ -2276,6 +2330,7 @@ static std::mutex g_tune_mu;
 // RG_CONV_TUNE_CACHE=<file>: measured choices are appended to the file (one line of 17 integers per geometry) and loaded from it by
 // the next process, which then measures only what it has not seen — profiling runs (no measuring launches inside the trace) and
 // runs that must repeat another process's kernels bit for bit use it
+static const int kMaxCand = 16;          // candidates of one measured choice (3 kernel implementations; up to 16 tile / split plans)
 static void tune_cache_load_locked() {
     static bool loaded = false;
     if (loaded) return;
@@ -2289,7 +2344,7 @@ static void tune_cache_load_locked() {
         bool ok = true;
         for (int i = 0; i < 16 && ok; ++i) ok = fscanf(f, "%d", &k[i]) == 1;
         if (!ok || fscanf(f, "%d", &choice) != 1) break;
-        g_tune[k] = choice < 0 ? 0 : (choice > 2 ? 2 : choice);
+        g_tune[k] = choice < 0 ? 0 : (choice >= kMaxCand ? kMaxCand - 1 : choice);
     }
     fclose(f);
 }
@@ -2315,7 +2370,7 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, i
     }
     if (!tune_enabled()) { run(0); return 0; }
     static const int tune8 = getenv("RG_CONV_TUNE8") ? atoi(getenv("RG_CONV_TUNE8")) : 1;      // 0: the eight-wave form is not a candidate
-    if (!tune8 && ncand > 2) ncand = 2;
+    if (!tune8 && ncand == 3 && family_bit != 0) ncand = 2;
     {                                 // the lock covers the table only, never a launch: measurements may nest (path choice below)
         std::unique_lock<std::mutex> lock(g_tune_mu);
         tune_cache_load_locked();
@@ -2333,11 +2388,15 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, i
         run(0);                       // no host synchronisation inside a capture: round-3 kernel, nothing recorded
         return 0;
     }
-    hipEvent_t ev[6];
+    if (ncand > kMaxCand) ncand = kMaxCand;
+    hipEvent_t ev[2 * kMaxCand];
     bool ok = true;
-    for (int i = 0; i < 6; ++i) ok = hipEventCreate(&ev[i]) == hipSuccess && ok;
-    float t[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < 2 * ncand; ++i) ok = hipEventCreate(&ev[i]) == hipSuccess && ok;
+    float t[kMaxCand] = {0.f};
     if (ok) {
+        // the candidates are timed on an otherwise idle GPU: work other streams were given earlier (weight gradients on the side
+        // stream, D_pd on the auxiliary stream) would otherwise run beside some candidates and not others
+        (void)hipDeviceSynchronize();
         for (int c = 0; c < ncand; ++c) run(c);       // warm-up (first launch of a code object loads it)
         for (int c = 0; c < ncand; ++c) {
             ok = hipEventRecord(ev[2 * c], stream) == hipSuccess && ok;
@@ -2347,7 +2406,7 @@ static int choose_impl(int family_bit, const TuneKey& key, hipStream_t stream, i
         ok = hipEventSynchronize(ev[2 * ncand - 1]) == hipSuccess && ok;
         for (int c = 0; c < ncand && ok; ++c) ok = hipEventElapsedTime(&t[c], ev[2 * c], ev[2 * c + 1]) == hipSuccess;
     }
-    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
+    for (int i = 0; i < 2 * ncand; ++i) (void)hipEventDestroy(ev[i]);
     if (!ok) {
         (void)hipGetLastError();
         run(0);
@@ -2538,8 +2597,9 @@ extern "C" size_t rg_conv2d_fwd_workspace(int N, int C, int K, int KH, int KW, i
         const int64_t Ng = (int64_t)N * P * Q;
         return (size_t)rg::cdiv(C, thin_fwd_per_slice(C, Ng)) * (size_t)K * (size_t)Ng * sizeof(float);
     }
-    const GemmPlan pl = plan_gemm(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, true);
-    size_t need = pl.splits > 1 ? (size_t)pl.splits * K * (size_t)N * P * Q * sizeof(float) : 0;
+    GemmPlan cands[kMaxCand];
+    const int nc = plan_candidates(K, (int64_t)N * P * Q, (int64_t)C * KH * KW, cands, kMaxCand);
+    size_t need = plans_workspace(cands, nc, K, (int64_t)N * P * Q);
     int hpv, wh, slab;
     if (KH == 3 && KW == 3 && C % BK == 0 && K >= 64 && halo_enabled() && halo_geom(P, Q, &hpv, &wh, &slab)) {   // stride 1 / pad 1: P x Q = H x W
         const size_t hn = halo_workspace(K, (int64_t)N * P * Q, C);
@@ -2616,7 +2676,12 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             bmode = 1;
             if (!is1x1) p.w = w_krsc;
         }
-        GemmPlan pl = plan_gemm(p.M, p.Ng, p.Kg, true);
+        GemmPlan cands[kMaxCand];
+        int nc = plan_candidates(p.M, p.Ng, p.Kg, cands, kMaxCand);
+        if (nc > 1 && (plans_workspace(cands, nc, p.M, p.Ng) > workspace_bytes || !workspace)) nc = 1;     // not the queried scratch
+        const ConvP pg = p;
+        auto run_plan = [&](GemmPlan pl) -> int {
+        p = pg;
         const size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float) : 0;
         if (need > workspace_bytes || (need && !workspace)) {     // no scratch given: run unsplit
             pl.splits = 1;
@@ -2643,6 +2708,18 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
         }
         return rg::check_launch("rg_conv2d_fwd");
+        };
+        if (nc > 1) {
+            int st = RG_OK;
+            const TuneKey pk = {64, N, C, H, W, K, KH, KW, SH, SW, PH, PW, bmode * 2 + (avec ? 1 : 0), nc, 0,
+                                (int)(pg.ep.res != nullptr) * 4 + pg.ep.act};
+            choose_impl(0, pk, stream, nc, [&](int c) {
+                const int e = run_plan(cands[c]);
+                if (e) st = e;
+            });
+            return st;
+        }
+        return run_plan(cands[0]);
     };
     if (halo_ok) {
         if (!tune_enabled() || !path_tune_enabled()) return launch_halo();
@@ -2672,14 +2749,16 @@ extern "C" int rg_conv_set_planes(int mask) {
     return old;
 }
 
-// number of (family, geometry) entries the first-call kernel chooser has measured so far; out[0] / out[1] (may be NULL): how many
-// of them went to the round-3 kernels / the plane path
+// number of choices the first-call chooser has measured so far (kernel implementation per (family, geometry, plan); tap-reuse vs
+// generic path and tile / split plan per geometry); out[0] / out[1] (may be NULL): how many of the kernel-implementation choices
+// went to the round-3 kernels / the plane path
 extern "C" int rg_conv_tune_stats(int* out) {
     std::lock_guard<std::mutex> lock(g_tune_mu);
     int n[2] = {0, 0};
-    for (const auto& kv : g_tune) ++n[kv.second ? 1 : 0];      // out[1]: plane path, four or eight waves
+    for (const auto& kv : g_tune)
+        if (kv.first[0] == 1 || kv.first[0] == 2 || kv.first[0] == 4) ++n[kv.second ? 1 : 0];      // out[1]: plane path, four or eight waves
     if (out) { out[0] = n[0]; out[1] = n[1]; }
-    return n[0] + n[1];
+    return (int)g_tune.size();
 }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
@@ -2708,8 +2787,10 @@ extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, i
         // one split more than planned: a padding whose classes order differently may plan one more
         return pl.splits > 1 ? (size_t)(pl.splits + 1) * C * (size_t)N * H * W * sizeof(float) : 0;
     }
-    const GemmPlan pl = plan_gemm(C, (int64_t)N * H * W, (int64_t)K * KH * KW, true);
-    size_t need = pl.splits > 1 ? (size_t)pl.splits * C * (size_t)N * H * W * sizeof(float) : 0;
+    GemmPlan cands[kMaxCand];
+    const int nc = plan_candidates(C, (int64_t)N * H * W, (int64_t)K * KH * KW, cands, kMaxCand);
+    size_t need = plans_workspace(cands, nc, C, (int64_t)N * H * W);
+    if (need >= (1ull << 31)) need = cands[0].splits > 1 ? (size_t)cands[0].splits * C * (size_t)N * H * W * sizeof(float) : 0;
     int hpv, wh, slab;
     if (KH == 3 && KW == 3 && K % BK == 0 && C % 4 == 0 && C >= 64 && halo_enabled() && halo_geom(H, W, &hpv, &wh, &slab)) {
         const size_t hn = halo_workspace(C, (int64_t)N * H * W, K);
@@ -2877,6 +2958,31 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
         ng_total += dp.cls[i].Ngc;
     }
     dp.ng_total = (int)ng_total;
+    const int wn_of_tile[4] = {2, 2, 2, 4};               // wave columns of the tile shapes in RG_TILE_SWITCH
+    auto cols_of = [&](const GemmPlan& q) -> int {
+        if (q.splits > 1) return 0;
+        int nts = 0;
+        for (int i = 0; i < SH * SW; ++i) nts += rg::cdiv(dp.cls[i].Ngc, kTileBN[q.tile]);
+        return nts * wn_of_tile[q.tile];
+    };
+    // measured plan choice (plan_candidates) for the one-class launches: with fused row sums only plans that write the column count
+    // the caller sized (rg_conv2d_dgrad_rowsum_cols reports the model's plan) qualify
+    GemmPlan cands[kMaxCand];
+    int nc = 1;
+    cands[0] = pl;
+    if (one_class && !dry) {
+        GemmPlan all[kMaxCand];
+        const int na = plan_candidates(p.M, ng_max, kg_max, all, kMaxCand);
+        if (na > 1 && all[0].tile == pl.tile && all[0].splits == pl.splits && workspace &&
+            plans_workspace(all, na, p.M, ng_max) <= workspace_bytes && plans_workspace(all, na, p.M, ng_max) < (1ull << 31)) {
+            const int want = cols_of(pl);
+            for (int i = 1; i < na; ++i)
+                if (!rowsum || cols_of(all[i]) == want) cands[nc++] = all[i];
+        }
+    }
+    const DgradP dp0 = dp;
+    auto run_plan = [&](GemmPlan pl) -> int {
+    dp = dp0;
     size_t need = pl.splits > 1 ? (size_t)pl.splits * p.M * (size_t)(one_class ? ng_max : ng_total) * sizeof(float) : 0;
     if (need >= (1ull << 31) || (!dry && (need > workspace_bytes || (need && !workspace)))) {
         pl.splits = 1;
@@ -2894,7 +3000,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
         nt_sum += dp.cls[i].ntiles;
         if (dp.cls[i].ntiles > nt_max) nt_max = dp.cls[i].ntiles;
     }
-    const int wn_waves = pl.tile == 3 ? 4 : 2;            // wave columns of the tile shapes in RG_TILE_SWITCH
+    const int wn_waves = wn_of_tile[pl.tile];
     const int cols = pl.splits > 1 ? 0 : nt_sum * wn_waves;
     if (dry) {
         *dry = cols;
@@ -2936,6 +3042,18 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
                                 p.partial, dx, dp, pl.splits, make_fastdiv(H * W), make_fastdiv(W), make_fastdiv(N * H * W));
     }
     return rg::check_launch("rg_conv2d_dgrad");
+    };
+    if (nc > 1) {
+        int st = RG_OK;
+        const TuneKey pk = {128, N, C, H, W, K, KH, KW, SH, SW, PH, PW, mode, nc, rowsum ? rowsum_cols : 0,
+                            (int)(residual != nullptr) * 16 + (int)(relu_mask != nullptr) * 8 + (int)(rowsum != nullptr) * 4 + act};
+        choose_impl(0, pk, stream, nc, [&](int c) {
+            const int e = run_plan(cands[c]);
+            if (e) st = e;
+        });
+        return st;
+    }
+    return run_plan(cands[0]);
 }
 }  // namespace
 
@@ -3018,13 +3136,46 @@ static WgradPlan plan_wgrad(int M, int Ng, int64_t Kg) {
 }
 }  // namespace
 
+namespace {
+// Measured split depth (choose_impl, like plan_candidates for the forward / data-gradient GEMMs): the model's split count first,
+// then 1/2, 3/4, 3/2 and 2x of it (multiples of 8 from 8 up: the kernel's split -> XCD mapping), >= 8 k-tiles per split.  What is
+// timed is the whole call: kernel + split-K reduction (+ folded-BatchNorm finish).
+static int wgrad_plan_candidates(int M, int Ng, int64_t Kg, WgradPlan* out, int max_out) {
+    out[0] = plan_wgrad(M, Ng, Kg);
+    int n = 1;
+    if (!plan_tune_enabled() || !tune_enabled() || getenv("RG_WGRAD_WG")) return n;
+    const int64_t nk = rg::cdiv64(Kg, BK);
+    const int base = out[0].splits;
+    const int alts[4] = {base / 2, base * 3 / 4, base * 3 / 2, base * 2};
+    for (int i = 0; i < 4 && n < max_out; ++i) {
+        int64_t sp = alts[i];
+        if (sp >= 8) sp = (sp + 4) / 8 * 8;
+        if (sp < 1) sp = 1;
+        if (sp > 512) sp = 512;
+        if (sp > 1 && nk / sp < 8) continue;
+        if (sp * (int64_t)M * Ng * 4 >= (1ll << 31)) continue;
+        WgradPlan pl = out[0];
+        pl.ktiles_per_split = (int)rg::cdiv64(nk, sp);
+        pl.splits = sp >= 8 ? (int)sp : (int)rg::cdiv64(nk, pl.ktiles_per_split);
+        if (pl.splits > nk) continue;
+        bool dup = false;
+        for (int j = 0; j < n; ++j) dup = dup || out[j].splits == pl.splits;
+        if (!dup) out[n++] = pl;
+    }
+    return n;
+}
+}  // namespace
+
 extern "C" size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q) {
     if (thin_filter(K, KH, KW)) {
         const int64_t Ng = (int64_t)N * P * Q;
         return (size_t)rg::cdiv64(Ng, thin_wgrad_per_slice(C, Ng)) * (size_t)K * (size_t)C * KH * KW * sizeof(float);
     }
-    const WgradPlan pl = plan_wgrad(K, C * KH * KW, (int64_t)N * P * Q);
-    return (size_t)pl.splits * (size_t)K * (size_t)C * KH * KW * sizeof(float);
+    WgradPlan cands[8];
+    const int nc = wgrad_plan_candidates(K, C * KH * KW, (int64_t)N * P * Q, cands, 8);
+    int smax = 0;
+    for (int i = 0; i < nc; ++i) smax = cands[i].splits > smax ? cands[i].splits : smax;
+    return (size_t)smax * (size_t)K * (size_t)C * KH * KW * sizeof(float);
 }
 
 extern "C" int rg_bn_fold_wgrad(const float* w, float* g, const float* scale, const float* invstd, const float* running_mean,
@@ -3076,7 +3227,13 @@ int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, 
             return fold ? fold_after(fold, dw, K, p.Ng, stream) : RG_OK;
         }
     }
-    const WgradPlan pl = plan_wgrad(p.M, p.Ng, p.Kg);
+    WgradPlan cands[8];
+    int nc = wgrad_plan_candidates(p.M, p.Ng, p.Kg, cands, 8);
+    for (int i = 1; i < nc; ++i)                 // a caller with the model plan's scratch only: the model's plan only
+        if (!workspace || (size_t)cands[i].splits * p.M * (size_t)p.Ng * sizeof(float) > workspace_bytes) nc = 1;
+    const ConvP pw0 = p;
+    auto run_plan = [&](const WgradPlan& pl) -> int {
+    p = pw0;
     p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles;
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     const size_t need = (size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float);      // see rg_conv2d_wgrad_workspace
@@ -3150,6 +3307,17 @@ int wgrad_impl(const float* x, const float* dy, float* dw, int N, int C, int H, 
     }
     if (int e = rg::check_launch("rg_conv2d_wgrad(reduce)")) return e;
     return fold ? fold_after(fold, dw, K, C * KH * KW, stream) : RG_OK;
+    };
+    if (nc > 1) {
+        int st = RG_OK;
+        const TuneKey pk = {256, N, C, H, W, K, KH, KW, SH, SW, PH, PW, fold ? 1 : 0, nc, cands[0].splits, 0};
+        choose_impl(0, pk, stream, nc, [&](int c) {
+            const int e = run_plan(cands[c]);
+            if (e) st = e;
+        });
+        return st;
+    }
+    return run_plan(cands[0]);
 }
 }  // namespace
 

@@ -295,6 +295,25 @@ extern "C" int rg_fill(float* y, int64_t n, float v, hipStream_t stream) {
     return rg::check_launch("rg_fill");
 }
 
+// One wave that does nothing for `us` microseconds of the constant-rate wall clock (bounded loop: every lane leaves after at most
+// 2^24 polls whatever the clock says).  rg_hip.ops.concurrent_stream launches it on two streams to find out whether they share a
+// hardware queue: kernels of streams mapped onto the same queue run one after the other.
+__global__ void spin_kernel(long long ticks, unsigned* sink) {
+    const long long t0 = wall_clock64();
+    unsigned polls = 0;
+    while (wall_clock64() - t0 < ticks && polls < (1u << 24)) ++polls;
+    if (sink && polls == 0xffffffffu) *sink = polls;
+}
+
+extern "C" int rg_spin_us(int us, hipStream_t stream) {
+    RG_REQUIRE(us > 0 && us <= 100000, "rg_spin_us: us must be in 1..100000");
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000;                               // the constant 100 MHz counter of gfx9
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)us * khz / 1000, (unsigned*)nullptr);
+    return rg::check_launch("rg_spin_us");
+}
+
 extern "C" int rg_sub_square_fwd(const float* a, const float* b, float* y, int64_t n, hipStream_t stream) {
     RG_REQUIRE(a && b && y && n >= 0, "rg_sub_square_fwd: bad arguments");
     if (n == 0) return RG_OK;

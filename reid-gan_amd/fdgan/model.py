@@ -165,7 +165,7 @@ class FDGANModel(object):
             return None
         s = getattr(self, "_aux", None)
         if s is None:
-            s = self._aux = torch.cuda.Stream(device=self.device)
+            s = self._aux = ops.concurrent_stream(self.device, avoid=(torch.cuda.current_stream(),))
         return s
 
     def set_input(self, input):

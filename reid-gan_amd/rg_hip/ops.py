@@ -195,13 +195,71 @@ def conv2d_dgrad(dy, w, x_hw, stride=1, padding=0, scale=None, shift=None, resid
 _SIDE = {"on": os.environ.get("RG_WGRAD_STREAM", "1") != "0", "sessions": {}}
 
 
+# ---- streams that really run side by side --------------------------------------------------------------------------------
+# HIP streams of one priority are mapped onto GPU_MAX_HW_QUEUES (default 4) hardware queues, least-used-first, and a hardware queue
+# runs its packets in order.  Which queue a new stream lands on depends on everything created before it (torch's pool of 32 streams,
+# RCCL's internal streams, ...): measured on config 2, the weight-gradient side stream sharing the main stream's queue costs the
+# whole overlap (38.2 instead of 34.7 ms per step at GPU_MAX_HW_QUEUES=2; 39.0 instead of 34.8 with a process group and 3 queues:
+# tools/debug/rccl_ab.sh).  So a second stream is PROBED, once, when it is created: an idle 150 us wave on each of two streams
+# takes ~150 us when they run side by side and ~300 us when they share a queue; the first of up to 8 pool streams that runs beside
+# every stream in `avoid` (earlier ones matter more) is taken.  RG_STREAM_PROBE=0: the first pool stream, unprobed.
+_HANDED = {}                # device index -> streams handed out by concurrent_stream (kept apart from each other too)
+_PROBE_US = 150
+
+
+def _share_a_queue(a, b):
+    import time
+    best = None
+    for _ in range(3):
+        a.synchronize()
+        b.synchronize()
+        t0 = time.perf_counter()
+        lib.rg_spin_us(_PROBE_US, a.cuda_stream)
+        lib.rg_spin_us(_PROBE_US, b.cuda_stream)
+        a.synchronize()
+        b.synchronize()
+        dt = 1e6 * (time.perf_counter() - t0)
+        best = dt if best is None else min(best, dt)
+    if os.environ.get("RG_STREAM_PROBE_DEBUG") == "1":
+        import sys
+        sys.stderr.write("[stream probe] %#x vs %#x: %.0f us\n" % (a.cuda_stream, b.cuda_stream, best))
+    return best > 1.6 * _PROBE_US
+
+
+def concurrent_stream(device, avoid=()):
+    """A stream of `device` whose kernels run beside those of the streams in `avoid` and of the streams handed out earlier."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    first = torch.cuda.Stream(device=device)
+    handed = _HANDED.setdefault(device.index, [])
+    # the streams to stay apart from, most important first: the caller's, then the most recently handed out ones (four hardware queues)
+    apart = [s for s in list(avoid) + handed[::-1][:4] if s is not None]
+    if os.environ.get("RG_STREAM_PROBE", "1") == "0" or CAPTURING[0] or not apart:
+        handed.append(first)
+        del handed[:-8]
+        return first
+    with torch.cuda.device(device):
+        best, best_score, cand = first, None, first
+        for i in range(8):
+            score = tuple(not _share_a_queue(other, cand) for other in apart)      # compared lexicographically: earlier entries decide
+            if best_score is None or score > best_score:
+                best, best_score = cand, score
+            if all(score):
+                break
+            cand = torch.cuda.Stream(device=device)
+    handed.append(best)
+    del handed[:-8]
+    return best
+
+
 class _SideSession(object):
     """Side stream + in-flight operand references of ONE main stream (networks running concurrently on different
     streams each get their own)."""
     __slots__ = ("stream", "depth", "refs", "used")
 
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
+    def __init__(self, device, main):
+        self.stream = concurrent_stream(device, avoid=(main,))
         self.depth, self.refs, self.used = 0, [], False
 
 
@@ -210,7 +268,7 @@ def _side_session(create=True):
     key = (main.device.index, main.cuda_stream)
     sess = _SIDE["sessions"].get(key)
     if sess is None and create:
-        sess = _SideSession(main.device)
+        sess = _SideSession(main.device, main)
         _SIDE["sessions"][key] = sess
     return main, sess
 

@@ -29,6 +29,21 @@ class DataParallel(nn.Module):
         return self.module(*inputs, **kwargs)
 
 
+def init_process_group(rank, world, local_rank, **kw):
+    """`dist.init_process_group("nccl", ...)` for one process per GPU.  The collectives' stream stays in the DEFAULT-priority pool, on
+    purpose: HIP streams of one priority share `GPU_MAX_HW_QUEUES` (4) hardware queues and the step already drives four streams
+    (main, weight-gradient side stream, FD-GAN's auxiliary stream and its side stream); a FIFTH active hardware queue — a
+    high-priority collective stream, or GPU_MAX_HW_QUEUES=8 — makes the queue scheduler time-slice them and every cross-stream
+    dependency then waits for a slice: measured on one rank, config 2, 35.4 -> 46.9 ms (high-priority stream) and 56-66 ms
+    (8 queues) per step (`tools/debug/rccl_ab.sh`, `profiles/r04_hw_queues.txt`).  RG_NCCL_HIGH_PRIO=1 asks for the high-priority
+    stream anyway (A/B)."""
+    opts = None
+    if os.environ.get("RG_NCCL_HIGH_PRIO", "0") == "1":
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    return dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                   pg_options=opts, **kw)
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -216,6 +231,8 @@ def attach_stage_hooks(reducer, *modules):
     one rank (the hook returns at once while the reducer is inactive)."""
     from .resnet_trunk import TVResNet
     n = 0
+    if os.environ.get("RG_STAGE_BUCKETS", "1") == "0":       # A/B switch: one reduction per arena after the backward pass (round 3)
+        return 0
     for root in modules:
         root = getattr(root, "module", root)
         for m in root.modules():

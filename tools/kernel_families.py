@@ -41,7 +41,7 @@ FAMILY = {
     "maxpool_bwd_3x3s2_kernel": "pool", "maxpool_bwd_kernel": "pool", "maxpool_fwd_kernel": "pool", "sum_all_kernel": "pool",
     # eltwise.hip
     "act_bwd_kernel": "eltwise", "act_fwd_kernel": "eltwise", "axpby_kernel": "eltwise", "copy_channels_kernel": "eltwise",
-    "dropout_kernel": "eltwise", "fill_kernel": "eltwise", "l2norm_rows_bwd_kernel": "eltwise",
+    "dropout_kernel": "eltwise", "fill_kernel": "eltwise", "spin_kernel": "eltwise", "l2norm_rows_bwd_kernel": "eltwise",
     "l2norm_rows_fwd_kernel": "eltwise", "l2norm_channels_fwd_kernel": "eltwise", "l2norm_channels_bwd_kernel": "eltwise", "mix_rows_bwd_kernel": "eltwise", "mix_rows_fwd_kernel": "eltwise",
     "pair_cat_kernel": "eltwise", "sub_square_bwd_kernel": "eltwise", "sub_square_fwd_kernel": "eltwise",
     # loss.hip
