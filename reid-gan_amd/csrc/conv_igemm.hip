@@ -2783,9 +2783,14 @@ extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, i
         static const int strided_split = getenv("RG_DGRAD_STRIDED_SPLIT") ? atoi(getenv("RG_DGRAD_STRIDED_SPLIT")) : 1;
         if (!strided_split || (int64_t)C * N * H * W >= (1ll << 31)) return 0;
         const int64_t kg_deep = (int64_t)K * ((KH + SH - 1) / SH) * ((KW + SW - 1) / SW);      // the deepest class (dgrad_impl plans on it)
-        const GemmPlan pl = plan_gemm(C, ng_eff, kg_deep, true);
+        GemmPlan cands[kMaxCand];
+        const int nc = plan_candidates(C, ng_eff, kg_deep, cands, kMaxCand);
+        int smax = 1;
+        for (int i = 0; i < nc; ++i) smax = cands[i].splits > smax ? cands[i].splits : smax;
         // one split more than planned: a padding whose classes order differently may plan one more
-        return pl.splits > 1 ? (size_t)(pl.splits + 1) * C * (size_t)N * H * W * sizeof(float) : 0;
+        const size_t need = smax > 1 ? (size_t)(smax + 1) * C * (size_t)N * H * W * sizeof(float) : 0;
+        if (need < (1ull << 31)) return need;
+        return cands[0].splits > 1 ? (size_t)(cands[0].splits + 1) * C * (size_t)N * H * W * sizeof(float) : 0;
     }
     GemmPlan cands[kMaxCand];
     const int nc = plan_candidates(C, (int64_t)N * H * W, (int64_t)K * KH * KW, cands, kMaxCand);
@@ -2970,14 +2975,17 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     GemmPlan cands[kMaxCand];
     int nc = 1;
     cands[0] = pl;
-    if (one_class && !dry) {
+    if (!dry && (one_class || ng_eff > 0)) {
         GemmPlan all[kMaxCand];
-        const int na = plan_candidates(p.M, ng_max, kg_max, all, kMaxCand);
-        if (na > 1 && all[0].tile == pl.tile && all[0].splits == pl.splits && workspace &&
-            plans_workspace(all, na, p.M, ng_max) <= workspace_bytes && plans_workspace(all, na, p.M, ng_max) < (1ull << 31)) {
+        const int na = one_class ? plan_candidates(p.M, ng_max, kg_max, all, kMaxCand)
+                                 : plan_candidates(p.M, ng_eff, ssplit ? kg_max : kg_eff, all, kMaxCand);
+        // (strided classes: the partial columns of all classes lie side by side, ng_total columns per split)
+        const size_t ws_all = plans_workspace(all, na, p.M, one_class ? ng_max : ng_total);
+        if (na > 1 && all[0].tile == pl.tile && all[0].splits == pl.splits && workspace && ws_all <= workspace_bytes &&
+            ws_all < (1ull << 31)) {
             const int want = cols_of(pl);
             for (int i = 1; i < na; ++i)
-                if (!rowsum || cols_of(all[i]) == want) cands[nc++] = all[i];
+                if ((one_class || ssplit || all[i].splits == 1) && (!rowsum || cols_of(all[i]) == want)) cands[nc++] = all[i];
         }
     }
     const DgradP dp0 = dp;

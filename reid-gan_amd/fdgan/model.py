@@ -166,6 +166,10 @@ class FDGANModel(object):
         s = getattr(self, "_aux", None)
         if s is None:
             s = self._aux = ops.concurrent_stream(self.device, avoid=(torch.cuda.current_stream(),))
+            if os.environ.get("RG_AUX_SIDE", "0") != "1":
+                # D_pd's four weight gradients stay on the auxiliary stream: three compute streams + the collectives' stream are
+                # the four hardware queues the device schedules without time-slicing
+                ops.side_inline(s)
         return s
 
     def set_input(self, input):

@@ -253,13 +253,24 @@ def concurrent_stream(device, avoid=()):
     return best
 
 
+_INLINE_SIDE = set()
+
+
+def side_inline(stream):
+    """Networks run on `stream` launch their weight gradients on `stream` itself instead of a side stream of their own: the
+    number of ACTIVE hardware queues stays at four with a collective stream in the picture (main, its side stream, `stream`,
+    RCCL) — a fifth makes the queue scheduler time-slice (rg_hip.parallel.init_process_group)."""
+    _INLINE_SIDE.add(stream.cuda_stream)
+
+
 class _SideSession(object):
     """Side stream + in-flight operand references of ONE main stream (networks running concurrently on different
     streams each get their own)."""
     __slots__ = ("stream", "depth", "refs", "used")
 
     def __init__(self, device, main):
-        self.stream = concurrent_stream(device, avoid=(main,))
+        # a main stream registered with side_inline() keeps its weight gradients to itself (session stream = the stream itself)
+        self.stream = main if main.cuda_stream in _INLINE_SIDE else concurrent_stream(device, avoid=(main,))
         self.depth, self.refs, self.used = 0, [], False
 
 

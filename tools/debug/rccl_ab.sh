@@ -8,13 +8,15 @@ for i in 1 2; do
 for q in ${RG_AB_QUEUES:-2 3 4 8}; do
 echo plain-q$q; GPU_MAX_HW_QUEUES=$q $B 2>/dev/null | python -c "$P"
 echo rccl-q$q; GPU_MAX_HW_QUEUES=$q RG_FORCE_REDUCE=1 $B 2>/dev/null | python -c "$P"
-done
-done
-echo "unprobed streams (the state before):"
-for q in ${RG_AB_QUEUES:-2 3 4 8}; do
-echo old-rccl-q$q; RG_STREAM_PROBE=0 GPU_MAX_HW_QUEUES=$q RG_FORCE_REDUCE=1 $B 2>/dev/null | python -c "$P"
-done
-echo "high-priority collective stream:"
-for q in ${RG_AB_QUEUES:-2 3 4 8}; do
 echo hp-rccl-q$q; RG_NCCL_HIGH_PRIO=1 GPU_MAX_HW_QUEUES=$q RG_FORCE_REDUCE=1 $B 2>/dev/null | python -c "$P"
+done
+done
+echo "D_pd's weight gradients on a side stream of the auxiliary stream (a fourth compute stream: the state before):"
+for q in ${RG_AB_QUEUES:-2 3 4 8}; do
+echo aux-side-plain-q$q; RG_AUX_SIDE=1 GPU_MAX_HW_QUEUES=$q $B 2>/dev/null | python -c "$P"
+echo aux-side-rccl-q$q; RG_AUX_SIDE=1 GPU_MAX_HW_QUEUES=$q RG_FORCE_REDUCE=1 $B 2>/dev/null | python -c "$P"
+done
+echo "unprobed streams:"
+for q in ${RG_AB_QUEUES:-2 3 4 8}; do
+echo unprobed-rccl-q$q; RG_STREAM_PROBE=0 RG_AUX_SIDE=1 GPU_MAX_HW_QUEUES=$q RG_FORCE_REDUCE=1 $B 2>/dev/null | python -c "$P"
 done
