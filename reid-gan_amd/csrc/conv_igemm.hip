@@ -2218,8 +2218,9 @@ static GemmPlan plan_gemm(int M, int64_t Ng, int64_t Kg, bool allow_split) {
 // one split step on about a third of the ResNet geometries (tools/sweep_tiles.py, round 4: forward -6 %, data gradient -4 % with the
 // best forced plan per layer).  So the PLAN is a measured choice too: the model's plan first, then every other tile of the shape
 // class with 1 / 2 / 3 / 4 / 6 / 8 splits that keeps >= 4 k-tiles per split and <= 1 536 workgroups; an alternative has to beat the
-// model's plan by 3 % (choose_impl).  RG_CONV_TUNE_PLAN=0 / RG_CONV_TUNE=0 / a forced plan: the model's plan only.
+// model's plan by 3 % (choose_impl).  RG_CONV_TUNE_PLAN=0 / RG_CONV_TUNE=0 / a forced plan / a GEMM under 1 GFLOP: the model's plan only.
 static bool tune_enabled();
+static const double kPlanTuneMinFlop = 1.0e9;      // below 1 GFLOP a launch takes ~10 us whatever the plan: not worth ~100 timed launches
 static bool plan_tune_enabled() {
     static const int env = getenv("RG_CONV_TUNE_PLAN") ? atoi(getenv("RG_CONV_TUNE_PLAN")) : 1;
     return env != 0;
@@ -2237,6 +2238,7 @@ static int plan_candidates(int M, int64_t Ng, int64_t Kg, GemmPlan* out, int max
     out[0] = plan_gemm(M, Ng, Kg, true);
     int n = 1;
     if (g_force_tile >= 0 || g_force_splits >= 1 || !plan_tune_enabled() || !tune_enabled() || M <= 32) return n;
+    if (2.0 * M * (double)Ng * (double)Kg < kPlanTuneMinFlop) return n;      // launch-bound sizes: nothing to choose between
     const int64_t nk = rg::cdiv64(Kg > 0 ? Kg : 1, BK);
     int tiles[3], nt = 0;
     if (Ng >= 128) {
@@ -3152,6 +3154,7 @@ static int wgrad_plan_candidates(int M, int Ng, int64_t Kg, WgradPlan* out, int 
     out[0] = plan_wgrad(M, Ng, Kg);
     int n = 1;
     if (!plan_tune_enabled() || !tune_enabled() || getenv("RG_WGRAD_WG")) return n;
+    if (2.0 * M * (double)Ng * (double)Kg < kPlanTuneMinFlop) return n;
     const int64_t nk = rg::cdiv64(Kg, BK);
     const int base = out[0].splits;
     const int alts[4] = {base / 2, base * 3 / 4, base * 3 / 2, base * 2};

@@ -274,7 +274,14 @@ def test_dptn_step_fp8_declared_tolerance(dev):
     print("fp8 gradient cosines vs fp32 oracle (no kinks): min %.4f at %s, median %.4f over %d tensors"
           % (cs[worst], worst, sorted(cs.values())[len(cs) // 2], len(cs)))
     assert cs[worst] >= 0.92, (worst, cs[worst])
-    # ---- two optimizer steps: the losses track the fp32 run ----------------------------------------------------
+
+
+# default run: the forward / gradient bounds above, graphed == eager bit for bit in fp8 (tests/test_netgraph_gpu.py) and the config-5
+# bench line; the two CPU-oracle optimizer steps of this one take 15-30 s of host time
+@pytest.mark.slow
+def test_dptn_fp8_losses_track_the_fp32_oracle_over_two_steps(dev):
+    """third clause of the declared fp8 tolerance (test_dptn_step_fp8_declared_tolerance): after two optimizer steps the losses
+    are still within 5e-2 of the fp32 oracle's"""
     m2, om2 = _build(dev, "hinge", conv_dtype="fp8")
     for step, (got, ref, fake, ofake) in enumerate(_run_steps(m2, om2, dev, "hinge")):
         print("fp8 step %d losses %s" % (step, {k: round(got[k], 5) for k in NAMES}))

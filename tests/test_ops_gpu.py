@@ -917,6 +917,28 @@ def test_conv_kernel_choice_is_measured_once_and_results_do_not_change(dev):
         assert torch.equal(ops.conv2d_wgrad(x, dy, (80, 48, 3, 3), 2, 1), dw1)
     assert rglib.lib.rg_conv_tune_stats(None) == after
     _close(y1, F.conv2d(x.double().cpu(), w.double().cpu(), stride=2, padding=1), name="fwd (chosen kernel)")
+    # a geometry above 1 GFLOP also measures its tile / split-K PLAN (forward, data gradient, weight-gradient split depth): same
+    # contract — decided in the first call, the same bits afterwards, right against the fp64 reference
+    x = torch.randn(16, 128, 34, 18, generator=g).to(dev)
+    w = (torch.randn(256, 128, 3, 3, generator=g) * 0.03).to(dev)
+    before = rglib.lib.rg_conv_tune_stats(None)
+    y1 = ops.conv2d_fwd(x, w, 1, 1)
+    dy = torch.randn(y1.shape, generator=g).to(dev)
+    dx1 = ops.conv2d_dgrad(dy, w, (34, 18), 1, 1)
+    dw1 = ops.conv2d_wgrad(x, dy, (256, 128, 3, 3), 1, 1)
+    after = rglib.lib.rg_conv_tune_stats(None)
+    assert after >= before + 6, (before, after)            # three plan choices + at least one kernel choice each
+    for _ in range(2):
+        assert torch.equal(ops.conv2d_fwd(x, w, 1, 1), y1)
+        assert torch.equal(ops.conv2d_dgrad(dy, w, (34, 18), 1, 1), dx1)
+        assert torch.equal(ops.conv2d_wgrad(x, dy, (256, 128, 3, 3), 1, 1), dw1)
+    assert rglib.lib.rg_conv_tune_stats(None) == after
+    xd, wd, dyd = x.double().cpu().requires_grad_(True), w.double().cpu().requires_grad_(True), dy.double().cpu()
+    yd = F.conv2d(xd, wd, stride=1, padding=1)
+    yd.backward(dyd)
+    _close(y1, yd.detach(), name="fwd (chosen plan)")
+    _close(dx1, xd.grad, name="dgrad (chosen plan)")
+    _close(dw1, wd.grad, name="wgrad (chosen plan)")
 
 
 def test_concurrent_stream_runs_beside_the_streams_it_avoids(dev):
