@@ -447,7 +447,10 @@ def measure(w, args, dev, rank, world, use_dist, headline):
 
     # configurations whose networks replay captured launch programs capture them in their first calls (rg_hip.netgraph.WARMUP
     # eager calls per key, then one capturing call): those preparation steps come BEFORE the W warm-up steps of the contract
-    for i in range(w.capture_steps):
+    # ... and ONE preparation step for every configuration: the first call of each convolution geometry measures its kernel /
+    # plan candidates (csrc/conv_igemm.hip, choose_impl: ~0.5 s per configuration) and the second streams are probed
+    # (rg_hip.ops.concurrent_stream) — neither belongs into a timed step should the caller ask for zero warm-up steps
+    for i in range(max(1, w.capture_steps)):
         w.step()
     for i in range(warmup):
         w.step()
@@ -532,7 +535,7 @@ def measure(w, args, dev, rank, world, use_dist, headline):
         dist.barrier()
     ms_step = 1e3 * elapsed / steps
     return {"value": round(world * w.crops * steps / elapsed, 2), "ms_per_step": round(ms_step, 3), "steps": steps,
-            "warmup": warmup, "capture_steps": w.capture_steps, "host_enqueue_ms_per_step": round(1e3 * t_host / steps, 3),
+            "warmup": warmup, "capture_steps": max(1, w.capture_steps), "host_enqueue_ms_per_step": round(1e3 * t_host / steps, 3),
             "launch": w.launch_note,
             "losses": {k: round(float(v), 5) for k, v in losses.items()}, "roofline": roof,
             "step_tflops_algorithmic": round(w.gflop_per_crop * w.crops / 1e3 / (ms_step * 1e-3), 2)}

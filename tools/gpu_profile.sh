@@ -20,8 +20,8 @@ export RG_CONV_TUNE_CACHE=/tmp/rg_tune_$c.txt
 if [ "$what" = kernel ] || [ "$what" = all ]; then
   rm -rf /tmp/prof_$c
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python3 bench.py --config $c --no-others --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${tag}_c${c}_bench_under_rocprof.json 2> gpurun_out/${tag}_c${c}_prof.err || exit 1
-  # 10 timed + 3 warm-up + 1 serial warm-up + 3 profiled steps (+ 4 capture steps for the configurations with graphed networks)
-  nsteps=17; case $c in 4a|5) nsteps=21;; esac
+  # 10 timed + 3 warm-up + 1 serial warm-up + 3 profiled steps + 1 preparation step (4 capture steps for the configurations with graphed networks)
+  nsteps=18; case $c in 4a|5) nsteps=21;; esac
   python tools/prof_summary.py /tmp/prof_$c gpurun_out/${tag}_c${c}_kernel_summary_serial.csv --steps $nsteps || exit 1
 fi
 if [ "$what" = pmc ] || [ "$what" = all ]; then
@@ -31,8 +31,8 @@ if [ "$what" = pmc ] || [ "$what" = all ]; then
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${c}_$ctr -- python3 bench.py --config $c --no-others --no-cpu-baseline --steps 1 --warmup 1 --profile-steps 0 > /dev/null 2> gpurun_out/${tag}_c${c}_pmc_$ctr.err || exit 1
     python tools/prof_summary.py /tmp/pmc_${c}_$ctr gpurun_out/${tag}_c${c}_pmc_$ctr.csv || exit 1
   done
-  # steps per pass: 1 warm-up + 1 timed (+ 4 capture steps for the configurations with graphed networks)
-  psteps=2; case $c in 4a|5) psteps=6;; esac
+  # steps per pass: 1 warm-up + 1 timed + 1 preparation step (4 capture steps for the configurations with graphed networks)
+  psteps=3; case $c in 4a|5) psteps=6;; esac
   python tools/pmc_traffic.py gpurun_out/${tag}_c${c}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_c${c}_pmc_WRITE_SIZE.csv $psteps gpurun_out/${tag}_pmc_traffic.json $c
 fi
 if [ "$what" = sq ] || [ "$what" = all ]; then
