@@ -52,7 +52,9 @@ int rg_profile_collect(double* ms, double* flops, double* bytes, long long* call
 /* ---- convolution: implicit GEMM, fp32 tensors, split-bf16 arithmetic on v_mfma_f32_32x32x16_bf16 ----
  * (every fp32 operand is split exactly into three bf16 pieces and each product evaluated as the six partial products of weight
  * >= 2^-16 with fp32 accumulation: the error model of an fp32 FMA chain, csrc/conv_igemm.hip; -DRG_MATH=1 builds the fp32-MFMA
- * v_mfma_f32_32x32x2_f32 arithmetic of rounds 1-2)
+ * v_mfma_f32_32x32x2_f32 arithmetic of rounds 1-2).  Overflow is NOT fp32's: an operand that is +-Inf, or finite but above the
+ * largest bf16 (|x| >= 3.3961e38: its leading piece rounds to Inf), makes its products NaN (Inf - Inf in the split) where an fp32
+ * FMA chain would give +-Inf; nothing in the reference's training range comes within 30 orders of magnitude of that)
  * Replaces nn.Conv2d / nn.ConvTranspose2d of the ResNet-50 trunk (CC/clustercontrast/models/
  * resnet_ibn_a.py:70-159, FD/reid/models/resnet.py:65-75), CustomPoseGenerator
  * (FD/fdgan/networks.py:86-138) and NLayerDiscriminator (FD/fdgan/networks.py:206-232), and
