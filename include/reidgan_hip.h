@@ -108,6 +108,17 @@ int rg_conv_set_planes(int mask);
  * of a forward geometry and the tap-reuse-vs-generic path of a 3x3 layer are chosen the same way.  Returns the number of choices
  * measured so far; out[0] / out[1] (int[2], may be NULL): how many kernel choices went to the default kernels / the plane path. */
 int rg_conv_tune_stats(int* out);
+/* Split-K without the finishing launch.  Registers (count > 0) or removes (counters == NULL) the arrival counters of `stream`:
+ * `count` ZERO-INITIALISED 32-bit words of device memory that the caller keeps alive and never writes (the library does not
+ * allocate; launches on one stream are ordered and every launch leaves its counters at zero, so one buffer per stream serves all of
+ * them).  With counters registered, a split forward / unit-stride data-gradient launch on that stream with <= count output tiles
+ * finishes inside the convolution kernel: the last split of a tile to arrive sums the tile's partials in split order and applies
+ * the epilogue — the finishing kernel's values bit for bit, whichever split arrives last.  Without them, or inside a stream capture,
+ * the finishing kernel follows as before.  (Measured equal to the finishing kernel within +-1 % on the FD-GAN step: rg_hip registers
+ * counters only with RG_SPLITK_INKERNEL=1.) */
+int rg_conv_splitk_arrivals(void* counters, int count, rg_stream_t stream);
+/* test / development query: the number of split-K launches that finished inside the convolution kernel so far (this process) */
+int rg_conv_splitk_inkernel_count(void);
 size_t rg_conv2d_wgrad_workspace(int N, int C, int K, int KH, int KW, int P, int Q);
 int rg_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int K, int KH, int KW,
                     int SH, int SW, int PH, int PW, int P, int Q, void* workspace, size_t workspace_bytes,

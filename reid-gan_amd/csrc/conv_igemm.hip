@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -108,6 +109,8 @@ struct ConvP {
     // split-K (fwd / dgrad: partial tiles to `partial`; wgrad: to y)
     int ktiles_per_split, splits;
     float* partial;
+    unsigned* arrive;    // nullptr, or one arrival counter per output tile (zero between launches): the LAST split of a tile to arrive
+                         // sums the tile's partials and applies the epilogue itself — no finishing launch (splitk_arrive_finish)
     // buffer-resource sizes (bytes, < 2^31) of x / w / y / partial, and extra dividers for the (r,s)-major orders
     unsigned x_bytes, w_bytes, y_bytes, partial_bytes;
     FastDiv d_c, d_k;
@@ -131,6 +134,7 @@ struct Tile {
     static constexpr int LDB = BN + LPAD;
     static constexpr int WTM = BM / WM;
     static constexpr int WTN = BN / WN;
+    static constexpr int TBM = BM, TBN = BN, NTHREADS = 64 * WM * WN;
     static constexpr int TM = WTM / 32;
     static constexpr int TN = WTN / 32;
     static_assert(WM * WN == 4 || WM * WN == 8, "4 waves per workgroup (8 for the plane-path kernels' 128 x 128 tile)");
@@ -323,6 +327,12 @@ __device__ __forceinline__ float4 bload4(rsrc_t r, unsigned off) {
 __device__ __forceinline__ void bstore(rsrc_t r, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
 }
+// AUX = 16: sc1, a write-through store (leaves the XCD's L2 for memory at once: what another XCD's workgroup may read in this launch)
+template <int AUX>
+__device__ __forceinline__ void bstore_aux(rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, AUX);
+}
+template <int I> struct AuxTag { static constexpr int value = I; };
 
 template <typename T>
 __device__ __forceinline__ void zero_acc(floatx16 (&acc)[T::TM][T::TN]) {
@@ -431,6 +441,87 @@ __device__ __forceinline__ void store_tile_epilogue_any(const ConvP& p, const fl
     }
 }
 
+// ---- split-K finish, four consecutive columns of one GEMM row (shared by conv_splitk_finish_vec_kernel and the in-kernel finish
+// below, so that the two produce the same bits): left-to-right sum over the splits, then the epilogue ----
+__device__ __forceinline__ float4 splitk_sum4(const float4* __restrict__ p4, int64_t sstride4, int64_t i, int splits) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        const float4 a = p4[(int64_t)s * sstride4 + i], b = p4[(int64_t)(s + 1) * sstride4 + i];
+        const float4 c = p4[(int64_t)(s + 2) * sstride4 + i], d = p4[(int64_t)(s + 3) * sstride4 + i];
+        v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+        v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < splits; ++s) {
+        const float4 a = p4[(int64_t)s * sstride4 + i];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void splitk_epilogue_store4(float* __restrict__ out, int64_t o, int m, float4 v, const Epilogue& ep) {
+    if (ep.scale) { const float sc = ep.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+    if (ep.shift) { const float sh = ep.shift[m]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+    if (ep.res) {
+        const float4 r = *reinterpret_cast<const float4*>(ep.res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    v.x = rg_apply_act(v.x, ep.act, ep.slope); v.y = rg_apply_act(v.y, ep.act, ep.slope);
+    v.z = rg_apply_act(v.z, ep.act, ep.slope); v.w = rg_apply_act(v.w, ep.act, ep.slope);
+    if (ep.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(ep.mask + o);
+        if (!(mk.x > 0.f)) v.x = 0.f;
+        if (!(mk.y > 0.f)) v.y = 0.f;
+        if (!(mk.z > 0.f)) v.z = 0.f;
+        if (!(mk.w > 0.f)) v.w = 0.f;
+    }
+    *reinterpret_cast<float4*>(out + o) = v;
+}
+
+// Split-K without the finishing launch (p.arrive != nullptr; the host sets it only when Ng % 4 == 0, PIX % 4 == 0 and every pointer is
+// 16-byte aligned).  The L2s of the eight XCDs are not coherent with each other inside a kernel and a CU's L1 is never refreshed by
+// other CUs' stores, so the hand-off follows the counter form of the split-K seam: every workgroup of a tile stores its raw
+// accumulators to partial[split] WRITE-THROUGH (sc1: no L2-wide release fence; __threadfence() here measured +27 us per launch),
+// every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, and one lane counts the workgroup in
+// on the tile's arrival counter (agent-scope atomic).  The workgroup that finds splits - 1 earlier arrivals is the last: one lane's
+// agent-scope acquire (drops this CU's stale L1 lines), the wait for it, a barrier — then all waves read the tile's partials back in
+// split order 0, 1, 2, ... (the finishing kernel's summation order: the result does not depend on which split came last) and write
+// the finished outputs.  atomicInc wraps the counter to zero on that last arrival: clean for the next launch without a memset (the
+// caller zeroes the counters once, rg_conv_splitk_arrivals).  Nobody waits for anybody: no workgroup can stall on one that has not
+// been scheduled yet.
+template <typename T>
+__device__ __forceinline__ void splitk_arrive_finish(const ConvP& p, int m0, int n0, int Ng, int PIX, const FastDiv& d_pix) {
+    __shared__ unsigned s_prev;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave: its write-through partial stores have left
+    __syncthreads();                                        // ... for all waves (and nobody reads operand LDS any more)
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicInc(p.arrive + blockIdx.x, (unsigned)p.splits - 1u);
+        if (prev == (unsigned)p.splits - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_prev = prev;
+    }
+    __syncthreads();
+    if (s_prev != (unsigned)p.splits - 1u) return;          // uniform
+    constexpr int C4 = T::TBN / 4, RSTEP = T::NTHREADS / C4;
+    static_assert(T::NTHREADS % C4 == 0, "whole rows per pass");
+    const int c4 = threadIdx.x % C4;
+    const int n = n0 + 4 * c4;
+    if (n >= Ng) return;
+    const int ng4 = Ng >> 2;
+    const int64_t sstride4 = (int64_t)p.M * ng4;
+    const float4* p4 = reinterpret_cast<const float4*>(p.partial);
+    const int im = fdiv(n, d_pix);
+    const int pix = n - im * PIX;
+    for (int r = threadIdx.x / C4; r < T::TBM; r += RSTEP) {
+        const int m = m0 + r;
+        if (m >= p.M) break;
+        const float4 v = splitk_sum4(p4, sstride4, (int64_t)m * ng4 + (n >> 2), p.splits);
+        splitk_epilogue_store4(p.y, ((int64_t)im * p.M + m) * PIX + pix, m, v, p.ep);
+    }
+}
+
 // Epilogue for outputs laid out [img][M][PIX] with n = img*PIX + pix (fwd: PIX = P*Q; stride-1 dgrad: PIX = H*W).
 // With split-K the raw accumulators go to partial[(split*M + m)*Ng + n] instead.  Buffer stores: one VALU add per
 // element, lanes outside the tensor carry OOB and are dropped by the hardware.
@@ -444,26 +535,34 @@ __device__ __forceinline__ void store_tile_nchw(const ConvP& p, const floatx16 (
     if (p.partial || plain) {
         const rsrc_t ro = p.partial ? make_rsrc(p.partial, p.partial_bytes) : make_rsrc(p.y, p.y_bytes);
         const unsigned rstride = (p.partial ? (unsigned)Ng : (unsigned)PIX) * 4u;    // bytes between GEMM rows
+        auto store_raw = [&](auto aux_tag) {
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            const int nn = n0 + wn * T::WTN + j * 32 + l32;
-            unsigned ob = OOB;
-            if (nn < Ng) {
-                if (p.partial) {
-                    ob = (unsigned)(((split * p.M + mrow0) * (int64_t)Ng + nn) * 4);
-                } else {
-                    const int im = fdiv(nn, d_pix);
-                    ob = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+            for (int j = 0; j < T::TN; ++j) {
+                const int nn = n0 + wn * T::WTN + j * 32 + l32;
+                unsigned ob = OOB;
+                if (nn < Ng) {
+                    if (p.partial) {
+                        ob = (unsigned)(((split * p.M + mrow0) * (int64_t)Ng + nn) * 4);
+                    } else {
+                        const int im = fdiv(nn, d_pix);
+                        ob = (unsigned)((((int64_t)im * p.M + mrow0) * PIX + (nn - im * PIX)) * 4);
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
+                        const unsigned off = (mrow0 + mo < p.M) ? ob + (unsigned)mo * rstride : OOB;
+                        bstore_aux<decltype(aux_tag)::value>(ro, off, acc[i][j][r]);
+                    }
             }
-#pragma unroll
-            for (int i = 0; i < T::TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mo = i * 32 + (r & 3) + 8 * (r >> 2);
-                    const unsigned off = (mrow0 + mo < p.M) ? ob + (unsigned)mo * rstride : OOB;
-                    bstore(ro, off, acc[i][j][r]);
-                }
+        };
+        if (p.partial && p.arrive) {                            // uniform
+            store_raw(AuxTag<16>());
+            splitk_arrive_finish<T>(p, m0, n0, Ng, PIX, d_pix);
+        } else {
+            store_raw(AuxTag<0>());
         }
         return;
     }
@@ -1588,37 +1687,10 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_vec_kernel(const float
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = fdiv((int)i, d_ng4);
         const int n = ((int)i - m * ng4) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int s = 0;
-        for (; s + 4 <= splits; s += 4) {
-            const float4 a = p4[(int64_t)s * sstride4 + i], b = p4[(int64_t)(s + 1) * sstride4 + i];
-            const float4 c = p4[(int64_t)(s + 2) * sstride4 + i], d = p4[(int64_t)(s + 3) * sstride4 + i];
-            v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
-            v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
-        }
-        for (; s < splits; ++s) {
-            const float4 a = p4[(int64_t)s * sstride4 + i];
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
+        const float4 v = splitk_sum4(p4, sstride4, i, splits);
         const int im = fdiv(n, d_pix);
         const int pix = n - im * PIX;
-        const int64_t o = ((int64_t)im * M + m) * PIX + pix;
-        if (ep.scale) { const float sc = ep.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-        if (ep.shift) { const float sh = ep.shift[m]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
-        if (ep.res) {
-            const float4 r = *reinterpret_cast<const float4*>(ep.res + o);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-        }
-        v.x = rg_apply_act(v.x, ep.act, ep.slope); v.y = rg_apply_act(v.y, ep.act, ep.slope);
-        v.z = rg_apply_act(v.z, ep.act, ep.slope); v.w = rg_apply_act(v.w, ep.act, ep.slope);
-        if (ep.mask) {
-            const float4 mk = *reinterpret_cast<const float4*>(ep.mask + o);
-            if (!(mk.x > 0.f)) v.x = 0.f;
-            if (!(mk.y > 0.f)) v.y = 0.f;
-            if (!(mk.z > 0.f)) v.z = 0.f;
-            if (!(mk.w > 0.f)) v.w = 0.f;
-        }
-        *reinterpret_cast<float4*>(out + o) = v;
+        splitk_epilogue_store4(out, ((int64_t)im * M + m) * PIX + pix, m, v, ep);
     }
 }
 
@@ -2120,6 +2192,7 @@ static void fill_common(ConvP& p, int N, int C, int H, int W, int K, int KH, int
     p.ktiles_per_split = 1 << 30;
     p.splits = 1;
     p.partial = nullptr;
+    p.arrive = nullptr;
     p.x_bytes = p.w_bytes = p.y_bytes = p.partial_bytes = 0;
     p.d_c = make_fastdiv(C);
     p.d_k = make_fastdiv(K);
@@ -2280,6 +2353,42 @@ static unsigned finish_grid(int64_t n) {
 static bool splitk_vec() {
     static const int env = getenv("RG_SPLITK_VEC") ? atoi(getenv("RG_SPLITK_VEC")) : 1;
     return env != 0;
+}
+
+// ---- arrival counters for split-K without the finishing launch (rg_conv_splitk_arrivals) ----
+// The library never allocates: the caller registers, per stream, a zero-initialised buffer of 32-bit counters that stays alive and is
+// touched by nothing else.  Launches on one stream are ordered and every launch leaves its counters at zero (atomicInc wraps on the
+// last arrival), so one buffer per stream serves every launch on it.  Not used inside a stream capture: a captured launch would carry
+// the capture stream's counters into replays on whatever stream the graph is launched on, next to eager launches that use them.
+// Measured (profiles/r04_splitk_inkernel.txt): a wash — the FD-GAN step 34.24-34.34 ms with the finishing kernels, 34.53-34.62 ms with
+// the in-kernel finish on the same box (what a launch boundary costs, 1.5-1.9 us, is what the last arriver's acquire and its serial
+// read of the tile's partials cost), so rg_hip registers counters only on request (RG_SPLITK_INKERNEL=1) and the default stays the
+// finishing kernel.  The first form tried — __threadfence() in every workgroup — cost +27 us per split launch (36.9 vs 32.8 ms).
+struct Arrivals { unsigned* ptr; int count; };
+static std::map<hipStream_t, Arrivals> g_arrivals;
+static std::mutex g_arrivals_mu;
+static std::atomic<int> g_inkernel_launches{0};
+// the counters a one-class split-K launch of `tiles` output tiles on `stream` may use, or nullptr (-> finishing kernel): the in-kernel
+// finish moves float4s, so it takes the vector finisher's conditions
+static unsigned* splitk_arrivals(hipStream_t stream, int tiles, const float* partial, const float* out, int M, int Ng, int PIX,
+                                 const Epilogue& ep) {
+    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ep.res) |
+                      reinterpret_cast<uintptr_t>(ep.mask)) & 15) == 0;
+    if (!al || (Ng & 3) || (PIX & 3) || (int64_t)M * Ng >= (1ll << 31) || ep.rowsum) return nullptr;
+    Arrivals a = {nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_arrivals_mu);
+        auto it = g_arrivals.find(stream);
+        if (it != g_arrivals.end()) a = it->second;
+    }
+    if (!a.ptr || tiles > a.count) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ++g_inkernel_launches;
+    return a.ptr;
 }
 
 static void launch_finish(hipStream_t stream, const float* partial, float* out, int M, int Ng, int PIX, const FastDiv& d_pix,
@@ -2484,6 +2593,7 @@ static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, voi
     p.splits = pl.splits;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = pl.splits > 1 ? (unsigned)((size_t)pl.splits * p.M * (size_t)p.Ng * sizeof(float)) : 0u;
+    p.arrive = pl.splits > 1 ? splitk_arrivals(stream, pl.m_tiles * pl.n_tiles, p.partial, p.y, p.M, p.Ng, H * W, p.ep) : nullptr;
     hp.c = p;
     hp.Cred = Cred;
     hp.HP = HPv; hp.Wh = Wh; hp.slab = slab;
@@ -2503,7 +2613,7 @@ static int halo_launch(ConvP& p, int Cred, int H, int W, const HaloPlan& pl, voi
         if (small) hipLaunchKernelGGL((conv3x3_halo_kernel<64, DGRAD, 13>), grid, dim3(NT), 0, stream, hp);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<64, DGRAD, 18>), grid, dim3(NT), 0, stream, hp);
     }
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && !p.arrive) {
         if (int e = rg::check_launch(op)) return e;
         launch_finish(stream, p.partial, p.y, p.M, p.Ng, H * W, make_fastdiv(H * W), pl.splits, p.ep);
     }
@@ -2693,6 +2803,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
         p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
         p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
         p.partial_bytes = (unsigned)need;
+        p.arrive = pl.splits > 1 ? splitk_arrivals(stream, p.m_tiles * p.n_tiles, p.partial, y, p.M, p.Ng, P * Q, p.ep) : nullptr;
         rg::ProfScope prof(rg::FAM_CONV_FWD, stream, 2.0 * p.M * (double)p.Ng * p.Kg, ALG_BYTES);
         const dim3 grid(p.m_tiles * p.n_tiles, pl.splits, 1);
         const TuneKey tk = {1, N, C, H, W, K, KH, KW, SH, SW, PH, PW, bmode * 2 + (avec ? 1 : 0), pl.tile, pl.splits,
@@ -2705,7 +2816,7 @@ extern "C" int rg_conv2d_fwd(const float* x, const float* w, const float* w_krsc
             else if (impl) { RG_TILE_SWITCH(pl.tile, RG_FWD_PL_LAUNCH); }
             else { RG_TILE_SWITCH(pl.tile, RG_FWD_LAUNCH); }
         });
-        if (pl.splits > 1) {
+        if (pl.splits > 1 && !p.arrive) {
             if (int e = rg::check_launch("rg_conv2d_fwd")) return e;
             launch_finish(stream, p.partial, y, p.M, p.Ng, P * Q, p.d_pq, pl.splits, p.ep);
         }
@@ -2762,6 +2873,23 @@ extern "C" int rg_conv_tune_stats(int* out) {
     if (out) { out[0] = n[0]; out[1] = n[1]; }
     return (int)g_tune.size();
 }
+
+// Registers (count > 0) or removes (counters == NULL) the arrival counters of split-K launches on `stream`: `count` zero-initialised
+// 32-bit words that the caller keeps alive and never writes.  With them the split forward / unit-stride data-gradient launches on
+// that stream finish inside the convolution kernel (the last split of a tile to arrive sums the tile's partials in split order: the
+// finishing kernel's values bit for bit); without them — or for launches with more tiles than `count`, or inside a stream capture —
+// a finishing kernel follows as before.
+extern "C" int rg_conv_splitk_arrivals(void* counters, int count, hipStream_t stream) {
+    RG_REQUIRE(!counters || count > 0, "rg_conv_splitk_arrivals: count must be positive");
+    RG_REQUIRE((reinterpret_cast<uintptr_t>(counters) & 3) == 0, "rg_conv_splitk_arrivals: counters must be 4-byte aligned");
+    std::lock_guard<std::mutex> lock(g_arrivals_mu);
+    if (counters) g_arrivals[stream] = Arrivals{static_cast<unsigned*>(counters), count};
+    else g_arrivals.erase(stream);
+    return RG_OK;
+}
+
+// test / development query: split-K launches that finished inside the convolution kernel so far (this process)
+extern "C" int rg_conv_splitk_inkernel_count(void) { return g_inkernel_launches.load(); }
 
 extern "C" size_t rg_conv2d_dgrad_workspace(int N, int C, int H, int W, int K, int KH, int KW, int SH, int SW) {
     if (SH != 1 || SW != 1) {
@@ -3025,6 +3153,8 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
     p.splits = pl.splits; p.ktiles_per_split = pl.ktiles_per_split;
     p.partial = pl.splits > 1 ? static_cast<float*>(workspace) : nullptr;
     p.partial_bytes = (unsigned)need;
+    p.arrive = (pl.splits > 1 && one_class) ? splitk_arrivals(stream, p.m_tiles * nt_max, p.partial, dx, p.M, (int)ng_max, H * W, p.ep)
+                                            : nullptr;
     rg::ProfScope prof(rg::FAM_CONV_DGRAD, stream, flops, ALG_BYTES);
     const dim3 grid(p.m_tiles * nt_max, pl.splits, SH * SW);
     static const int dma_env = getenv("RG_CONV_DMA") ? atoi(getenv("RG_CONV_DMA")) : 1;
@@ -3045,7 +3175,7 @@ int dgrad_impl(const float* dy, const float* w, const float* w_krsc, float* dx, 
             RG_TILE_SWITCH(pl.tile, RG_DGRAD_LAUNCH);
         }
     });
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && !p.arrive) {
         if (int e = rg::check_launch("rg_conv2d_dgrad")) return e;
         if (one_class) launch_finish(stream, p.partial, dx, p.M, (int)ng_max, H * W, make_fastdiv(H * W), pl.splits, p.ep);
         else hipLaunchKernelGGL(conv_splitk_finish_strided_kernel, dim3(finish_grid((int64_t)p.M * N * H * W)), dim3(256), 0, stream,

@@ -83,7 +83,7 @@ def build(verbose=False):
     return LIB_PATH
 
 
-_PLAIN_INT = {"rg_version", "rg_family_count", "rg_fold_chunk", "rg_bn_slices", "rg_conv2d_dgrad_rowsum_cols", "rg_f8_grad_tiles", "rg_krsc_chunk", "rg_conv_set_planes", "rg_conv_tune_stats"}   # int-returning queries that are not status codes
+_PLAIN_INT = {"rg_version", "rg_family_count", "rg_fold_chunk", "rg_bn_slices", "rg_conv2d_dgrad_rowsum_cols", "rg_f8_grad_tiles", "rg_krsc_chunk", "rg_conv_set_planes", "rg_conv_tune_stats", "rg_conv_splitk_inkernel_count"}   # int-returning queries that are not status codes
 
 
 class _Lib(object):

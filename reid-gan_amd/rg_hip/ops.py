@@ -5,9 +5,8 @@ otherwise (there is deliberately no CPU path).
 """
 from __future__ import absolute_import
 
-import os
-
 import ctypes
+import os
 
 import torch
 
@@ -67,15 +66,27 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
+_SPLITK_INKERNEL = os.environ.get("RG_SPLITK_INKERNEL", "0") not in ("", "0")
+
+
 class _Workspace(object):
     """One growing scratch buffer per (device, stream); kernels on a stream are ordered, so reuse is safe."""
+
+    ARRIVALS = 4096      # arrival counters per stream (split-K launches have at most 1 536 workgroups: <= 768 tiles)
 
     def __init__(self):
         self.bufs = {}
         self.pinned = {}
+        self.arrivals = {}
 
     def get(self, nbytes, device):
         key = (device.index, _stream())
+        if _SPLITK_INKERNEL and key not in self.arrivals and not CAPTURING[0]:
+            # RG_SPLITK_INKERNEL=1: split-K convolutions on this stream finish inside the kernel (rg_conv_splitk_arrivals) — measured
+            # equal to the finishing kernel, so off by default; zeroed once, the launches leave the counters at zero; never freed,
+            # never written from here
+            cnt = self.arrivals[key] = torch.zeros(self.ARRIVALS, dtype=torch.int32, device=device)
+            lib.rg_conv_splitk_arrivals(cnt.data_ptr(), self.ARRIVALS, key[1])
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -88,6 +99,26 @@ class _Workspace(object):
 
 
 _ws = _Workspace()
+
+
+def splitk_inkernel(enable):
+    """(tests, A/B runs) register or remove the current stream's split-K arrival counters: with them the split forward /
+    unit-stride data-gradient launches finish inside the convolution kernel, without them a finishing kernel follows — the same
+    bits either way.  Returns whether they were registered before."""
+    d = _DEV[0]
+    if d is None:
+        d = _DEV[0] = torch._C._cuda_getDevice()
+    key = (d, _stream())
+    cnt = _ws.arrivals.get(key)
+    was = cnt is not None and cnt is not False
+    if enable:
+        if not was:
+            cnt = _ws.arrivals[key] = torch.zeros(_Workspace.ARRIVALS, dtype=torch.int32, device=torch.device("cuda", d))
+            lib.rg_conv_splitk_arrivals(cnt.data_ptr(), _Workspace.ARRIVALS, key[1])
+    else:
+        _ws.arrivals[key] = False              # keeps _Workspace.get from registering again
+        lib.rg_conv_splitk_arrivals(None, 0, key[1])
+    return was
 
 
 _ws_sizes = {}

@@ -893,6 +893,74 @@ def test_conv_planes_kernels(dev, case, mask):
         rglib.lib.rg_conv_set_planes(old)
 
 
+# (N, C, H, W, K, k, stride, pad, forced tile (0: 128x128, 1: 64x128, 2: 64x64, 3: 32x256), forced splits); N*P*Q % 4 == 0
+SPLITK_CASES = [
+    (8, 256, 8, 4, 208, 1, 1, 0, 2, 4),     # 1x1, float4 pixel operand, ragged rows on 64 x 64 tiles
+    (4, 64, 16, 6, 96, 3, 1, 1, 1, 3),      # 3x3 (r,s)-major gather, 64 x 128 tiles, three splits (width 6: not a tap-reuse geometry)
+    (8, 160, 8, 6, 136, 3, 1, 1, 0, 5),     # 128 x 128 tiles (eight-wave candidate), five splits: the 4 + 1 summation tail
+    (2, 20, 12, 8, 40, 3, 1, 1, 3, 2),      # generic (c, r, s) gather, 32 x 256 tile, ragged columns
+    (32, 1024, 8, 4, 256, 1, 1, 0, 2, 8),   # a layer3-size 1x1 at the bench's 32 crops: many tiles race for the last arrival
+    (16, 128, 16, 8, 128, 3, 1, 1, 1, 4),   # tap-reuse geometry: conv3x3_halo_kernel plans its own splits and competes by measurement
+]
+
+
+@pytest.mark.parametrize("mask", [None, 7, 15])     # measured kernel choice / plane path, four waves / eight waves
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv_splitk_finishes_in_kernel_with_the_finishing_kernels_bits(dev, case, mask):
+    """split-K without the finishing launch (rg_conv_splitk_arrivals): the last split of a tile to arrive sums the tile's partials in
+    split order and applies the epilogue — the same bits as the finishing kernel, whichever workgroup came last, with every epilogue
+    term (scale, shift, residual, activation / ReLU mask), repeatedly (the counters clean themselves), and right against fp64"""
+    ops = _ops()
+    from rg_hip import lib as rglib
+    N, C, H, W, K, k, s, p, tile, splits = case
+    g = torch.Generator().manual_seed(777 + C + K)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, k, k, generator=g) / math.sqrt(C * k * k)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    y_ref = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    res = torch.randn(y_ref.shape, generator=g)
+    dy = torch.randn(y_ref.shape, generator=g)
+    dres = torch.randn(x.shape, generator=g)
+    xd = x.double().requires_grad_(True)
+    F.conv2d(xd, w.double(), stride=s, padding=p).backward(dy.double())
+    yf_ref = F.leaky_relu(y_ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double(), 0.2)
+    dx_ref = torch.where(x.double() > 0, xd.grad + dres.double(), torch.zeros_like(xd.grad))
+    X, Wt, SC, SH, RES, DY, DRES = (t.to(dev) for t in (x, w, sc, sh, res, dy, dres))
+
+    def run():
+        return (ops.conv2d_fwd(X, Wt, s, p), ops.conv2d_fwd(X, Wt, s, p, scale=SC, shift=SH, residual=RES, act=ops.ACT_LEAKY, slope=0.2),
+                ops.conv2d_dgrad(DY, Wt, (H, W), s, p), ops.conv2d_dgrad(DY, Wt, (H, W), s, p, residual=DRES, relu_mask=X))
+
+    old = rglib.lib.rg_conv_set_planes(mask) if mask is not None else None
+    rglib.lib.rg_conv_set_force(tile, splits)
+    ops._ws_sizes.clear()
+    was = ops.splitk_inkernel(True)
+    try:
+        c0 = rglib.lib.rg_conv_splitk_inkernel_count()
+        a = run()
+        c1 = rglib.lib.rg_conv_splitk_inkernel_count()
+        if k == 1 or W & (W - 1):                           # (tap-reuse geometries may run unsplit on the kernel's own plan)
+            assert c1 >= c0 + 4, (c0, c1)                   # all four launches finished in the kernel
+        b = run()                                           # the counters are clean again
+        ops.splitk_inkernel(False)
+        c2 = rglib.lib.rg_conv_splitk_inkernel_count()
+        f = run()                                           # the finishing kernel
+        assert rglib.lib.rg_conv_splitk_inkernel_count() == c2
+        for i, name in enumerate(("fwd", "fwd + epilogue", "dgrad", "dgrad + residual + mask")):
+            assert torch.equal(a[i], f[i]), name + ": in-kernel finish differs from the finishing kernel"
+            assert torch.equal(a[i], b[i]), name + ": second in-kernel run differs (stale counters?)"
+        _close(a[0], y_ref, name="fwd (split-K in kernel)")
+        _close(a[1], yf_ref, name="fwd + epilogue (split-K in kernel)")
+        _close(a[2], xd.grad, name="dgrad (split-K in kernel)")
+        _close(a[3], dx_ref, name="dgrad + residual + mask (split-K in kernel)")
+    finally:
+        ops.splitk_inkernel(was)
+        rglib.lib.rg_conv_set_force(-1, -1)
+        ops._ws_sizes.clear()
+        if old is not None:
+            rglib.lib.rg_conv_set_planes(old)
+
+
 def test_conv_kernel_choice_is_measured_once_and_results_do_not_change(dev):
     """the first call of a geometry times the round-3 kernel and the plane path and keeps the faster; the output of that first call
     already comes from the kept kernel, so repeating the call gives the same bits (fwd, dgrad, wgrad)"""
