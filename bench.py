@@ -13,8 +13,9 @@ input: batch_size 16 pairs = 32 crops of 256x128 + 18-channel pose maps per GPU,
     4b  joint step with FDGANModel in the GAN role (north-star wording), 32 crops = 16 pairs          (fdgan/adaptor.py)
     5   dual_gan DPTNModel step (two generator branches), fp8 MFMA convolutions, 64 crops at 128x64    (DPTN_model.py:216-225)
 
-and, unless --no-others is given, the default run also measures each of them briefly and reports them under
-`other_configs` of the same JSON line, so one driver-run line covers every configuration.
+and, unless --no-others is given, the default single-GPU run also measures each of them briefly and reports them under
+`other_configs` of the same JSON line, so one driver-run line covers every configuration (multi-GPU runs: the headline
+only, unless --others asks for the DDP configurations 4a / 4b / 5 behind it).
 
 Multi-GPU: weak scaling, one rank per GPU, gradients all-reduced over RCCL.  `--gpus N` without a torch.distributed
 environment starts the N ranks itself (a `python -m torch.distributed.run` child process, created before this process
@@ -561,7 +562,8 @@ def self_launch(args):
     if args.dry_run:
         print(json.dumps({"dry_run": True, "ranks": args.gpus, "cmd": cmd,
                           "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")},
-                          "configs_measured": [args.config] + ([] if args.no_others or args.config != "2" else OTHERS_DIST)}),
+                          "configs_measured": [args.config] + (OTHERS_DIST if args.others and not args.no_others and args.config == "2"
+                                                                 else [])}),
               file=_real_stdout)
         _real_stdout.flush()
         return 0
@@ -584,6 +586,9 @@ def main():
     ap.add_argument("--other-steps", type=int, default=8, help="timed steps of each configuration under other_configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="measure only --config")
+    ap.add_argument("--others", action="store_true",
+                    help="multi-GPU runs measure only the headline unless this is given (then BASELINE.json's DDP configurations 4a / 4b / "
+                         "5 follow it under other_configs); single-GPU runs measure the other configurations by default")
     ap.add_argument("--dry-run", action="store_true",
                     help="with --gpus N outside torch.distributed.run: print the child command that would start the ranks (one "
                          "JSON line) and exit without touching a GPU")
@@ -622,7 +627,9 @@ def main():
             log("cpu baseline done: %.3f images/s" % cpu["value"])
 
     others = None
-    if not args.no_others and args.config == "2":
+    # N > 1: the headline only, unless --others — the line the driver's scaling curve is computed from must not depend on the graphed
+    # configurations (4a, 5) getting through their first multi-rank run (no N > 1 run exists yet: DESIGN section 5)
+    if not args.no_others and args.config == "2" and (world == 1 or args.others):
         # the other BASELINE configurations, measured in the same process behind the headline.  Multi-GPU: the DDP
         # configurations of BASELINE.json — 4 (the joint trainer: 4a as committed in trainers_b.py:617-814, 4b with FDGANModel
         # in the GAN role) and 5 (dual_gan DPTNModel, fp8) — so that their scaling curves come out of the same runs

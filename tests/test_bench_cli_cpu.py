@@ -30,8 +30,11 @@ def test_gpus_2_dry_run_prints_the_child_command():
     tail = cmd[cmd.index("--master-port") + 3:]
     assert tail == ["--gpus", "2", "--steps", "4", "--warmup", "1"]          # --dry-run is not forwarded to the ranks
     assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # BASELINE.json's DDP configurations (4 = joint trainer, 5 = dual_gan fp8) ride behind the weak-scaling headline
-    assert d["configs_measured"] == ["2", "4a", "4b", "5"]
+    # a multi-GPU run measures the weak-scaling headline only ...
+    assert d["configs_measured"] == ["2"]
+    # ... unless --others asks for BASELINE.json's DDP configurations (4 = joint trainer, 5 = dual_gan fp8) behind it
+    d = _dry("--others")
+    assert d["configs_measured"] == ["2", "4a", "4b", "5"] and d["cmd"][-1] == "--others"
 
 
 def test_dry_run_with_a_single_config():
